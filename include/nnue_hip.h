@@ -1,0 +1,178 @@
+/*
+ * nnue_hip.h -- C ABI of libnnue_hip.so: the MI355X (gfx950) kernels behind the
+ * NNUE training hot path of marict/nnue-vision.
+ *
+ * The reference has no FFI seam for this path: the seam is the Python module
+ * surface of nnue.py.  This library is what a ctypes
+ * binding under that surface calls; every entry point below names the
+ * reference code (file:line under the reference root) whose arithmetic it
+ * replaces.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, ints, floats; no torch / C++ types;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*;
+ *     NULL = the null stream) and never synchronises, allocates or frees:
+ *     scratch memory is passed in, so calls can be captured into a hipGraph;
+ *   - tensors are dense row-major float32 unless stated; ids are int32 inside
+ *     the library and int64 at the reference boundary (nnue_ft_prepare);
+ *   - return 0 on success, a negative NNUE_E_* code otherwise; nothing throws.
+ *     nnue_hip_last_error() returns a thread-local description of the last
+ *     failure.  Arguments are validated BEFORE any launch: a call that returns
+ *     an error has launched nothing.
+ *   - all float pointers must be 16-byte aligned (torch allocations are).
+ *
+ * Active-feature list ("act list") layout shared by the calls below, capacity
+ * `cap` entries per sample:
+ *     rows[b*cap + k]  int32  table row, already clamped to [0, F-1]
+ *     coef[b*cap + k]  float  multiplier (feature value; 1.0 for binary features)
+ *     pos [b*cap + k]  int32  where the entry's value-gradient goes
+ *     n[b]             int32  number of valid entries of sample b (k < n[b])
+ * and the transposed coefficient matrix
+ *     coefT[f*ldb + b] float  sum of coef over the entries of sample b that map to row f
+ * with ldb >= B a multiple of 64.  Entries keep the caller's order.
+ */
+#ifndef NNUE_HIP_H
+#define NNUE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NNUE_HIP_ABI_VERSION 1
+
+#define NNUE_OK 0
+#define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
+#define NNUE_E_SHAPE (-2)   /* sizes inconsistent with each other */
+#define NNUE_E_LAUNCH (-3)  /* HIP reported a launch error */
+#define NNUE_E_SCRATCH (-4) /* scratch buffer too small */
+
+typedef void* nnue_stream_t; /* hipStream_t */
+
+int nnue_hip_abi_version(void);
+const char* nnue_hip_last_error(void);
+
+/* ---- front end ---------------------------------------------------------------- */
+
+/* nn.Conv2d(3, fps, 3, stride, padding=1, bias=False)  (nnue.py:486-493, call :640).
+ * images [B,3,H,W], weight [fps,3,3,3] (OIHW), conv_out [B,fps,Gh,Gw] with
+ * Gh = (H-1)/stride + 1, Gw = (W-1)/stride + 1.  Each output is one fmaf chain over
+ * (ci, kh, kw) in that order, so results do not depend on the launch shape. */
+int nnue_conv3x3_forward(const float* images, const float* weight, float* conv_out,
+                         int B, int H, int W, int fps, int stride, nnue_stream_t stream);
+
+/* StraightThroughBinary.forward + NNUE._to_sparse_features  (nnue.py:19-25, :590-635)
+ * without the data-dependent width: per sample, ascending flat ids p = c*Gh*Gw + h*Gw + w
+ * with conv_out > thr[c], written as an act list of capacity P = fps*Gh*Gw
+ * (rows = min(p, F-1), pos = p, coef = 1) and as coefT [F, ldb] (rows < F-1: the bit;
+ * row F-1: the number of active ids >= F-1 -- the clamp of nnue.py:701).  Ids are bit-exact
+ * given conv_out.  Every element of rows/pos/coef beyond n[b] is left untouched;
+ * coefT is fully overwritten for b < B. */
+int nnue_binarize_features(const float* conv_out, const float* thr,
+                           int B, int fps, int Gh, int Gw, int F,
+                           int32_t* rows, int32_t* pos, float* coef, int32_t* n,
+                           float* coefT, int ldb, nnue_stream_t stream);
+
+/* Same ids in the reference's own format (nnue.py:609-633): idx [B,M] int64 padded with -1,
+ * val [B,M] float32 padded with 0, from an act list whose max n[b] the caller has read
+ * back (M = max(max n, 1)). */
+int nnue_act_to_padded(const int32_t* pos, const float* coef, const int32_t* n, int cap,
+                       int B, int M, int64_t* idx, float* val, nnue_stream_t stream);
+
+/* StraightThroughBinary.backward for the threshold + conv weight gradient
+ * (nnue.py:28-54; autograd of the conv at nnue.py:640).
+ *   d_thr[c]            = -sum_{b,h,w} d_conv_out * k*s*(1-s),  s = sigmoid(k*(x - thr[c])), k = 10
+ *   d_weight[c,ci,kh,kw] = sum_{b,h,w} d_conv_out[b,c,h,w] * images[b,ci,h*stride+kh-1,w*stride+kw-1]
+ * Deterministic two-stage sum; scratch >= nnue_ste_conv_backward_scratch(...) bytes. */
+int64_t nnue_ste_conv_backward_scratch(int B, int fps, int Gh, int Gw);
+int nnue_ste_conv_backward(const float* images, const float* conv_out, const float* thr,
+                           const float* d_conv_out, int B, int H, int W, int fps, int stride,
+                           float* d_thr, float* d_weight, void* scratch, int64_t scratch_bytes,
+                           nnue_stream_t stream);
+
+/* ---- FeatureTransformer ------------------------------------------------------- */
+
+/* Turns the reference-format inputs of FeatureTransformer.forward (nnue.py:686: idx int64
+ * [B,M], -1 = padding, any order, repeats allowed; val float32 [B,M]) into an act list of
+ * capacity M (valid entries compacted in order, rows clamped as nnue.py:701, pos = original
+ * column) and coefT [F, ldb].  coefT is zeroed by the call.  Repeats accumulate. */
+int nnue_ft_prepare(const int64_t* idx, const float* val, int B, int M, int F,
+                    int32_t* rows, int32_t* pos, float* coef, int32_t* n,
+                    float* coefT, int ldb, nnue_stream_t stream);
+
+/* FeatureTransformer.forward  (nnue.py:686-710):
+ *   out[b,:] = bias + sum_{k<n[b]} coef[b,k] * weight[rows[b,k], :]
+ * weight [F,L1], out [B,L1]. */
+int nnue_ft_forward(const float* weight, const float* bias,
+                    const int32_t* rows, const float* coef, const int32_t* n, int cap,
+                    int B, int F, int L1, float* out, nnue_stream_t stream);
+
+/* Gradient of the above w.r.t. weight and bias (autograd IndexBackward + index_put_
+ * (accumulate) of nnue.py:702-708), as a per-row gather-sum over coefT -- no atomics,
+ * bitwise reproducible:
+ *   d_weight[f,:] = sum_b coefT[f,b] * d_out[b,:]      d_bias = sum_b d_out[b,:]
+ * Either output may be NULL. */
+int nnue_ft_backward_weight(const float* d_out, const float* coefT, int ldb,
+                            int B, int F, int L1, float* d_weight, float* d_bias,
+                            nnue_stream_t stream);
+
+/* Gradient w.r.t. the feature values (autograd of nnue.py:705-707):
+ *   dst[b*dst_ld + pos[b,k]] = < d_out[b,:], weight[rows[b,k],:] >   for k < n[b]
+ * dst is zero-filled first ([B, dst_ld]); dst_ld = M for the stand-alone op, P when the
+ * values are the binary map (the gradient then IS d_conv_out, nnue.py:628-633 + :33). */
+int nnue_ft_backward_values(const float* d_out, const float* weight,
+                            const int32_t* rows, const int32_t* pos, const int32_t* n, int cap,
+                            int B, int F, int L1, float* dst, int dst_ld, nnue_stream_t stream);
+
+/* ---- pairwise product + SimpleClassifier -------------------------------------- */
+
+/* Forward of  l0 = cat(x[:, :L1/2] * x[:, L1/2:], x[:, :L1/2])  (nnue.py:660-666, when
+ * `pairwise` != 0; l0 = x otherwise) followed by Linear(L1,L2)+act, Linear(L2,L3)+act,
+ * Linear(L3,C)  (nnue.py:728-734).  act = ReLU, or min(ReLU, clip) when clip > 0 (build
+ * extension, off = reference).  Saves h1 [B,L2], h2 [B,L3] (post-activation) for backward.
+ * scratch >= nnue_classifier_scratch(B, L1, L2, L3) bytes (covers forward and backward). */
+int64_t nnue_classifier_scratch(int B, int L1, int L2, int L3);
+int nnue_classifier_forward(const float* x, int pairwise,
+                            const float* w1, const float* b1, const float* w2, const float* b2,
+                            const float* w3, const float* b3, float clip,
+                            int B, int L1, int L2, int L3, int C,
+                            float* h1, float* h2, float* logits,
+                            void* scratch, int64_t scratch_bytes, nnue_stream_t stream);
+
+/* Backward of the above (autograd of nnue.py:660-669 and :728-734 in the reference).  d_x [B,L1]
+ * is the gradient w.r.t. x (through the pairwise block when `pairwise`); NULL skips it.  Weight/bias gradients are overwritten, not accumulated. */
+int nnue_classifier_backward(const float* x, int pairwise,
+                             const float* w1, const float* w2, const float* w3, float clip,
+                             const float* h1, const float* h2, const float* d_logits,
+                             int B, int L1, int L2, int L3, int C,
+                             float* d_x, float* d_w1, float* d_b1, float* d_w2, float* d_b2,
+                             float* d_w3, float* d_b3,
+                             void* scratch, int64_t scratch_bytes, nnue_stream_t stream);
+
+/* ---- loss + step tail ---------------------------------------------------------- */
+
+/* F.cross_entropy(logits, labels) (mean over the batch, train.py:250-254) and its gradient
+ * d_logits = (softmax - onehot) * grad_scale / B (may be NULL: forward only).
+ * sample_loss [B] receives the per-sample losses, loss (device scalar) their mean, summed in
+ * sample order (deterministic).  Labels outside [0, C) contribute loss 0 and a zero gradient
+ * row -- the caller validates labels; the kernel only stays in bounds. */
+int nnue_cross_entropy(const float* logits, const int64_t* labels, int B, int C, float grad_scale,
+                       float* sample_loss, float* loss, float* d_logits, nnue_stream_t stream);
+
+/* clip_grad_norm_ + SGD(momentum, weight_decay) on flat buffers (train.py:363-366, :457-464):
+ *   g <- g * grad_scale              (1/world after a summed all-reduce)
+ *   norm = ||g||_2 ; c = min(1, max_norm/(norm+1e-6)) if max_norm > 0 else 1
+ *   g <- c*g + wd*p ; m <- first_step ? g : momentum*m + g ; p <- p - lr*m
+ * norm_out (device float, may be NULL) receives the pre-clip norm.  Deterministic
+ * two-stage norm; scratch >= nnue_sgd_scratch(count) bytes. */
+int64_t nnue_sgd_scratch(int64_t count);
+int nnue_sgd_step(float* params, float* grads, float* momentum_buf, int64_t count,
+                  float lr, float momentum, float weight_decay, float max_norm, float grad_scale,
+                  int first_step, float* norm_out, void* scratch, int64_t scratch_bytes,
+                  nnue_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NNUE_HIP_H */

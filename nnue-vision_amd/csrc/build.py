@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Builds libnnue_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+The library is placed in-tree next to the host layer (nnue-vision_amd/nnue_hip/) so that it
+travels with the source snapshot; it is git-ignored.  Rebuilds only when a source is newer.
+"""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent
+ROOT = CSRC.parent.parent
+OUT = CSRC.parent / "nnue_hip" / "libnnue_hip.so"
+SOURCES = ["abi.cpp", "ft_kernels.hip", "feature_kernels.hip", "classifier_kernels.hip", "optim_kernels.hip"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result",
+         "-fno-gpu-rdc", "-x", "hip", f"-I{ROOT / 'include'}", f"-I{CSRC}"]
+
+
+def stale() -> bool:
+    if not OUT.exists():
+        return True
+    t = OUT.stat().st_mtime
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", ROOT / "include" / "nnue_hip.h", Path(__file__)]
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    if not force and not stale():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, *FLAGS, *[str(CSRC / s) for s in SOURCES], "-o", str(OUT)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,543 @@
+// Pairwise product + SimpleClassifier (nnue.py:660-666, :713-738) forward and backward on gfx950.
+//
+//   l0 = pairwise ? cat(x[:, :h] * x[:, h:], x[:, :h]) : x           (h = L1/2; never materialised)
+//   h1 = act(l0 W1^T + b1)   h2 = act(h1 W2^T + b2)   logits = h2 W3^T + b3
+//
+// Only the L1-wide layer is a real contraction (B x L1 x L2; 134 MFLOP at B=512, 1024 -> 128).  It
+// runs on the f32 MFMA (v_mfma_f32_16x16x4_f32, exact fp32 products, fp32 accumulate) when the
+// shape allows (L1 % 32 == 0, L2 % 16 == 0), split over K so that >= 512 waves are in flight, and
+// on plain-VALU "simple" kernels otherwise.  The two narrow layers (L2 -> L3 -> C) are a per-sample
+// tail kernel working out of LDS.  Split-K partials are summed in fixed order: reproducible.
+#include "common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
+  return v;
+}
+
+__device__ __forceinline__ float act_fn(float z, float clip) {
+  const float r = fmaxf(z, 0.0f);
+  return clip > 0.0f ? fminf(r, clip) : r;
+}
+__device__ __forceinline__ float gate_fn(float h, float clip) {
+  return (h > 0.0f && (clip <= 0.0f || h < clip)) ? 1.0f : 0.0f;
+}
+
+// element k of the (virtual) l0 row built from x row `xr`
+__device__ __forceinline__ float l0_at(const float* __restrict__ xr, int k, int half, int pairwise) {
+  if (!pairwise) return xr[k];
+  return k < half ? xr[k] * xr[k + half] : xr[k - half];
+}
+
+// ------------------------------------------------------------------ layer 1, any shape
+// wave per output (b, j): lanes stride over K; pre-activation, bias not yet added.
+__global__ __launch_bounds__(256) void l1_forward_simple(const float* __restrict__ x, int pairwise,
+                                                         const float* __restrict__ w1, int B, int L1, int L2,
+                                                         float* __restrict__ part) {
+  const long long o = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= (long long)B * L2) return;
+  const int b = (int)(o / L2), j = (int)(o - (long long)b * L2);
+  const int lane = threadIdx.x & 63, half = L1 / 2;
+  const float* __restrict__ xr = x + (size_t)b * L1;
+  const float* __restrict__ wr = w1 + (size_t)j * L1;
+  float acc = 0.f;
+  for (int k = lane; k < L1; k += 64) acc = fmaf(l0_at(xr, k, half, pairwise), wr[k], acc);
+  acc = wave_sum(acc);
+  if (lane == 0) part[o] = acc;
+}
+
+// d_w1[i, j] = sum_b d_z1[b, i] * l0[b, j]; thread per (i, j)
+__global__ __launch_bounds__(256) void l1_backward_w_simple(const float* __restrict__ x, int pairwise,
+                                                            const float* __restrict__ d_z1, int B, int L1, int L2,
+                                                            float* __restrict__ d_w1) {
+  const int i = blockIdx.x;
+  const int j = blockIdx.y * 256 + threadIdx.x;
+  if (j >= L1) return;
+  const int half = L1 / 2;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) acc = fmaf(d_z1[(size_t)b * L2 + i], l0_at(x + (size_t)b * L1, j, half, pairwise), acc);
+  d_w1[(size_t)i * L1 + j] = acc;
+}
+
+// d_l0 = d_z1 W1, then the pairwise block's own backward; thread per (b, j)
+__global__ __launch_bounds__(256) void l1_backward_x_simple(const float* __restrict__ x, int pairwise,
+                                                            const float* __restrict__ w1,
+                                                            const float* __restrict__ d_z1, int B, int L1, int L2,
+                                                            float* __restrict__ d_x) {
+  const int b = blockIdx.x;
+  const int j = blockIdx.y * 256 + threadIdx.x;
+  const int half = L1 / 2;
+  const float* __restrict__ dz = d_z1 + (size_t)b * L2;
+  if (pairwise) {
+    if (j >= half) return;
+    float lo = 0.f, hi = 0.f;
+    for (int k = 0; k < L2; ++k) {
+      lo = fmaf(dz[k], w1[(size_t)k * L1 + j], lo);
+      hi = fmaf(dz[k], w1[(size_t)k * L1 + j + half], hi);
+    }
+    const float* __restrict__ xr = x + (size_t)b * L1;
+    d_x[(size_t)b * L1 + j] = fmaf(lo, xr[j + half], hi);
+    d_x[(size_t)b * L1 + j + half] = lo * xr[j];
+  } else {
+    if (j >= L1) return;
+    float acc = 0.f;
+    for (int k = 0; k < L2; ++k) acc = fmaf(dz[k], w1[(size_t)k * L1 + j], acc);
+    d_x[(size_t)b * L1 + j] = acc;
+  }
+}
+
+// ------------------------------------------------------------------ layer 1 on the f32 MFMA
+// Lane map of v_mfma_f32_16x16x4_f32: lane l = 16*q + r supplies A[row r][k q] and B[k q][col r];
+// accumulator register t holds D[row 4*q + t][col r].
+//
+// Forward ("NT": both operands contiguous along K).  A wave owns a 16-sample x 64-unit tile and a
+// K slice.  Each lane loads float4 along K, i.e. K elements kb + 4q .. 4q+3, and MFMA step t uses
+// element t on BOTH operands -- a permutation of the K order, which a sum does not care about.
+constexpr int kFwdTileN = 4;  // 16x16 tiles along L2 per wave
+
+__global__ __launch_bounds__(256) void l1_forward_mfma(const float* __restrict__ x, int pairwise,
+                                                       const float* __restrict__ w1, int B, int L1, int L2,
+                                                       int ksplit, float* __restrict__ part) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int n_groups = (L2 + 16 * kFwdTileN - 1) / (16 * kFwdTileN);
+  const int m_tiles = (B + 15) / 16;
+  long long wid = (long long)blockIdx.x * 4 + wave;
+  if (wid >= (long long)m_tiles * n_groups * ksplit) return;
+  const int ks = (int)(wid % ksplit);
+  wid /= ksplit;
+  const int ng = (int)(wid % n_groups);
+  const int mt = (int)(wid / n_groups);
+  const int klen = L1 / ksplit;  // multiple of 16, inside one half when pairwise (ksplit even)
+  const int k_lo = ks * klen;
+  const int half = L1 / 2;
+  const int row = mt * 16 + r;
+  const bool row_ok = row < B;
+  const float* __restrict__ xr = x + (size_t)(row_ok ? row : 0) * L1;
+  // pairwise: first half of l0 = x[k] * x[k + half]; second half = x[k - half]
+  const bool prod = pairwise && k_lo < half;
+  const int xoff = (pairwise && !prod) ? -half : 0;
+
+  f32x4 acc[kFwdTileN];
+#pragma unroll
+  for (int t = 0; t < kFwdTileN; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* wrow[kFwdTileN];
+  bool col_ok[kFwdTileN];
+#pragma unroll
+  for (int t = 0; t < kFwdTileN; ++t) {
+    const int col = (ng * kFwdTileN + t) * 16 + r;
+    col_ok[t] = col < L2;
+    wrow[t] = w1 + (size_t)(col_ok[t] ? col : 0) * L1;
+  }
+  for (int kb = k_lo; kb < k_lo + klen; kb += 16) {
+    const int k = kb + 4 * q;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row_ok) {
+      a = *reinterpret_cast<const float4*>(xr + k + xoff);
+      if (prod) {
+        const float4 a2 = *reinterpret_cast<const float4*>(xr + k + half);
+        a.x *= a2.x; a.y *= a2.y; a.z *= a2.z; a.w *= a2.w;
+      }
+    }
+    float4 bv[kFwdTileN];
+#pragma unroll
+    for (int t = 0; t < kFwdTileN; ++t)
+      bv[t] = col_ok[t] ? *reinterpret_cast<const float4*>(wrow[t] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < kFwdTileN; ++t) {
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bv[t].x, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bv[t].y, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bv[t].z, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bv[t].w, acc[t], 0, 0, 0);
+    }
+  }
+  float* __restrict__ out = part + (size_t)ks * B * L2;
+#pragma unroll
+  for (int t = 0; t < kFwdTileN; ++t) {
+    const int col = (ng * kFwdTileN + t) * 16 + r;
+    if (col >= L2) continue;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int orow = mt * 16 + 4 * q + e;
+      if (orow < B) out[(size_t)orow * L2 + col] = acc[t][e];
+    }
+  }
+}
+
+// d_w1 = d_z1^T l0 ("TN": both operands contiguous along the non-K dimension; K = batch).  A wave
+// owns 2 x 4 tiles (32 units x 64 columns) and a slice of the batch; per K step (4 samples) every
+// lane loads one dword per tile row/column block.
+constexpr int kBwTileM = 2, kBwTileN = 4;
+
+__global__ __launch_bounds__(256) void l1_backward_w_mfma(const float* __restrict__ x, int pairwise,
+                                                          const float* __restrict__ d_z1, int B, int L1, int L2,
+                                                          int ksplit, int klen, float* __restrict__ part) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int m_groups = L2 / (16 * kBwTileM);  // L2 % 32 == 0
+  const int n_groups = L1 / (16 * kBwTileN);  // L1 % 64 == 0
+  long long wid = (long long)blockIdx.x * 4 + wave;
+  if (wid >= (long long)m_groups * n_groups * ksplit) return;
+  const int ks = (int)(wid % ksplit);
+  wid /= ksplit;
+  const int ng = (int)(wid % n_groups);
+  const int mg = (int)(wid / n_groups);
+  const int half = L1 / 2;
+  const int b_lo = ks * klen;
+  const int b_hi = min(B, b_lo + klen);
+  f32x4 acc[kBwTileM][kBwTileN];
+#pragma unroll
+  for (int i = 0; i < kBwTileM; ++i)
+#pragma unroll
+    for (int t = 0; t < kBwTileN; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // column j of l0 for each of this lane's N tiles; a 16-column tile never straddles `half` (half % 16 == 0)
+  int cj[kBwTileN], cj2[kBwTileN];
+#pragma unroll
+  for (int t = 0; t < kBwTileN; ++t) {
+    const int j = (ng * kBwTileN + t) * 16 + r;
+    if (!pairwise) { cj[t] = j; cj2[t] = -1; }
+    else if (j < half) { cj[t] = j; cj2[t] = j + half; }
+    else { cj[t] = j - half; cj2[t] = -1; }
+  }
+  for (int b0 = b_lo; b0 < b_hi; b0 += 4) {
+    const int b = b0 + q;
+    const bool ok = b < b_hi;
+    const float* __restrict__ dz = d_z1 + (size_t)(ok ? b : 0) * L2 + mg * 16 * kBwTileM + r;
+    const float* __restrict__ xr = x + (size_t)(ok ? b : 0) * L1;
+    float a[kBwTileM], bv[kBwTileN];
+#pragma unroll
+    for (int i = 0; i < kBwTileM; ++i) a[i] = ok ? dz[16 * i] : 0.f;
+#pragma unroll
+    for (int t = 0; t < kBwTileN; ++t) {
+      float v = ok ? xr[cj[t]] : 0.f;
+      if (cj2[t] >= 0 && ok) v *= xr[cj2[t]];
+      bv[t] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < kBwTileM; ++i)
+#pragma unroll
+      for (int t = 0; t < kBwTileN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv[t], acc[i][t], 0, 0, 0);
+  }
+  float* __restrict__ out = part + (size_t)ks * L2 * L1;
+#pragma unroll
+  for (int i = 0; i < kBwTileM; ++i)
+#pragma unroll
+    for (int t = 0; t < kBwTileN; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int orow = (mg * kBwTileM + i) * 16 + 4 * q + e;
+        const int ocol = (ng * kBwTileN + t) * 16 + r;
+        out[(size_t)orow * L1 + ocol] = acc[i][t][e];
+      }
+}
+
+// fixed-order sum of split-K slabs: out[i] = sum_s part[s][i]
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ part, int slabs, long long count,
+                                                       float* __restrict__ out) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= count) return;  // count % 4 == 0
+  float4 acc = *reinterpret_cast<const float4*>(part + i);
+  for (int s = 1; s < slabs; ++s) {
+    const float4 v = *reinterpret_cast<const float4*>(part + (size_t)s * count + i);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  *reinterpret_cast<float4*>(out + i) = acc;
+}
+
+// d_x = (d_z1 W1) through the pairwise block ("NN": A contiguous along K = L2, B along N).  A wave
+// owns 16 samples x two 16-column tiles: columns j and j + L1/2 when pairwise (the pairwise backward
+// needs both), adjacent tiles otherwise.
+__global__ __launch_bounds__(256) void l1_backward_x_mfma(const float* __restrict__ x, int pairwise,
+                                                          const float* __restrict__ w1,
+                                                          const float* __restrict__ d_z1, int B, int L1, int L2,
+                                                          float* __restrict__ d_x) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int half = L1 / 2;
+  const int n_pairs = L1 / 32;
+  const int m_tiles = (B + 15) / 16;
+  const long long wid = (long long)blockIdx.x * 4 + wave;
+  if (wid >= (long long)m_tiles * n_pairs) return;
+  const int np = (int)(wid % n_pairs);
+  const int mt = (int)(wid / n_pairs);
+  const int c0 = pairwise ? np * 16 : np * 32;
+  const int c1 = pairwise ? c0 + half : c0 + 16;
+  const int row = mt * 16 + r;
+  const bool row_ok = row < B;
+  const float* __restrict__ dz = d_z1 + (size_t)(row_ok ? row : 0) * L2;
+  f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  for (int kb = 0; kb < L2; kb += 16) {  // L2 % 16 == 0
+    const int k = kb + 4 * q;
+    const float4 a = row_ok ? *reinterpret_cast<const float4*>(dz + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* __restrict__ wk = w1 + (size_t)k * L1 + r;
+    float b0v[4], b1v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      b0v[e] = wk[(size_t)e * L1 + c0];
+      b1v[e] = wk[(size_t)e * L1 + c1];
+    }
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0v[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1v[0], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0v[1], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1v[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0v[2], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1v[2], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0v[3], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1v[3], acc1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int orow = mt * 16 + 4 * q + e;
+    if (orow >= B) continue;
+    float* __restrict__ o = d_x + (size_t)orow * L1;
+    if (pairwise) {
+      const float* __restrict__ xr = x + (size_t)orow * L1;
+      o[c0 + r] = fmaf(acc0[e], xr[c1 + r], acc1[e]);
+      o[c1 + r] = acc0[e] * xr[c0 + r];
+    } else {
+      o[c0 + r] = acc0[e];
+      o[c1 + r] = acc1[e];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ narrow layers (per sample, LDS)
+__global__ __launch_bounds__(128) void tail_forward_kernel(const float* __restrict__ part, int ksplit,
+                                                           const float* __restrict__ b1, const float* __restrict__ w2,
+                                                           const float* __restrict__ b2, const float* __restrict__ w3,
+                                                           const float* __restrict__ b3, float clip, int B, int L2,
+                                                           int L3, int C, float* __restrict__ h1,
+                                                           float* __restrict__ h2, float* __restrict__ logits) {
+  extern __shared__ float lds[];  // h1 [L2], h2 [L3]
+  float* h1s = lds;
+  float* h2s = lds + L2;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int j = tid; j < L2; j += 128) {
+    float z = b1[j];
+    for (int s = 0; s < ksplit; ++s) z += part[((size_t)s * B + b) * L2 + j];
+    const float h = act_fn(z, clip);
+    h1s[j] = h;
+    h1[(size_t)b * L2 + j] = h;
+  }
+  __syncthreads();
+  for (int j = tid; j < L3; j += 128) {
+    const float* __restrict__ wr = w2 + (size_t)j * L2;
+    float z = b2[j];
+    for (int k = 0; k < L2; ++k) z = fmaf(wr[k], h1s[k], z);
+    const float h = act_fn(z, clip);
+    h2s[j] = h;
+    h2[(size_t)b * L3 + j] = h;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 128) {
+    const float* __restrict__ wr = w3 + (size_t)c * L3;
+    float z = b3[c];
+    for (int k = 0; k < L3; ++k) z = fmaf(wr[k], h2s[k], z);
+    logits[(size_t)b * C + c] = z;
+  }
+}
+
+__global__ __launch_bounds__(128) void tail_backward_kernel(const float* __restrict__ d_logits,
+                                                            const float* __restrict__ h1, const float* __restrict__ h2,
+                                                            const float* __restrict__ w2, const float* __restrict__ w3,
+                                                            float clip, int L2, int L3, int C,
+                                                            float* __restrict__ d_z1, float* __restrict__ d_z2) {
+  extern __shared__ float lds[];  // d_logits [C], d_z2 [L3]
+  float* dls = lds;
+  float* dz2s = lds + C;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int c = tid; c < C; c += 128) dls[c] = d_logits[(size_t)b * C + c];
+  __syncthreads();
+  for (int j = tid; j < L3; j += 128) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s = fmaf(dls[c], w3[(size_t)c * L3 + j], s);
+    const float v = s * gate_fn(h2[(size_t)b * L3 + j], clip);
+    dz2s[j] = v;
+    d_z2[(size_t)b * L3 + j] = v;
+  }
+  __syncthreads();
+  for (int k = tid; k < L2; k += 128) {
+    float s = 0.f;
+    for (int j = 0; j < L3; ++j) s = fmaf(dz2s[j], w2[(size_t)j * L2 + k], s);
+    d_z1[(size_t)b * L2 + k] = s * gate_fn(h1[(size_t)b * L2 + k], clip);
+  }
+}
+
+// Small batch reductions, one wave per output element, lanes stride over the batch:
+//   d_w3 [C, L3] | d_b3 [C] | d_w2 [L3, L2] | d_b2 [L3] | d_b1 [L2]
+__global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restrict__ d_logits,
+                                                          const float* __restrict__ d_z2, const float* __restrict__ d_z1,
+                                                          const float* __restrict__ h1, const float* __restrict__ h2,
+                                                          int B, int L2, int L3, int C, float* __restrict__ d_w3,
+                                                          float* __restrict__ d_b3, float* __restrict__ d_w2,
+                                                          float* __restrict__ d_b2, float* __restrict__ d_b1) {
+  long long o = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const long long n_w3 = (long long)C * L3, n_w2 = (long long)L3 * L2;
+  const float* pa;
+  const float* pb = nullptr;
+  int sa, sb = 0;
+  float* dst;
+  if (o < n_w3) {
+    pa = d_logits + o / L3; sa = C; pb = h2 + o % L3; sb = L3; dst = d_w3 + o;
+  } else if ((o -= n_w3) < C) {
+    pa = d_logits + o; sa = C; dst = d_b3 + o;
+  } else if ((o -= C) < n_w2) {
+    pa = d_z2 + o / L2; sa = L3; pb = h1 + o % L2; sb = L2; dst = d_w2 + o;
+  } else if ((o -= n_w2) < L3) {
+    pa = d_z2 + o; sa = L3; dst = d_b2 + o;
+  } else if ((o -= L3) < L2) {
+    pa = d_z1 + o; sa = L2; dst = d_b1 + o;
+  } else {
+    return;
+  }
+  float acc = 0.f;
+  if (pb) {
+    for (int b = lane; b < B; b += 64) acc = fmaf(pa[(size_t)b * sa], pb[(size_t)b * sb], acc);
+  } else {
+    for (int b = lane; b < B; b += 64) acc += pa[(size_t)b * sa];
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) *dst = acc;
+}
+
+// ------------------------------------------------------------------ shape policy (shared by scratch + launch)
+struct ClsPlan {
+  bool fwd_mfma, bww_mfma, bwx_mfma;
+  int fwd_ksplit;            // K slabs of the forward partial sums
+  int bww_ksplit, bww_klen;  // batch slabs of d_w1
+};
+
+ClsPlan make_plan(int B, int L1, int L2, int pairwise) {
+  ClsPlan p{};
+  p.fwd_mfma = (L1 % 32 == 0) && (L2 % 16 == 0);
+  p.fwd_ksplit = 1;
+  if (p.fwd_mfma) {
+    // enough K slabs for >= ~1024 waves, each slab a multiple of 16 and (pairwise) inside one half
+    const int tiles = ((B + 15) / 16) * ((L2 + 63) / 64);
+    int ks = 1;
+    while (tiles * ks < 1024 && L1 % (ks * 2 * 16) == 0 && L1 / (ks * 2) >= 64) ks *= 2;
+    if (pairwise && ks == 1) ks = 2;
+    p.fwd_ksplit = ks;
+  }
+  p.bww_mfma = (L1 % 64 == 0) && (L2 % 32 == 0);
+  p.bww_ksplit = 1;
+  p.bww_klen = B;
+  if (p.bww_mfma) {
+    const int tiles = (L2 / 32) * (L1 / 64);
+    int ks = 1;
+    while (tiles * ks < 1024 && B / (ks * 2) >= 32) ks *= 2;
+    p.bww_ksplit = ks;
+    p.bww_klen = ((B + ks - 1) / ks + 3) / 4 * 4;
+  }
+  p.bwx_mfma = (L1 % 32 == 0) && (L2 % 16 == 0);
+  return p;
+}
+
+int64_t plan_scratch_floats(const ClsPlan& p, int B, int L1, int L2, int L3) {
+  const int64_t fwd = (int64_t)p.fwd_ksplit * B * L2;
+  const int64_t bwd = (int64_t)B * L2 + (int64_t)B * L3 + (p.bww_ksplit > 1 ? (int64_t)p.bww_ksplit * L2 * L1 : 0);
+  return (fwd > bwd ? fwd : bwd) + 64;
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" int64_t nnue_classifier_scratch(int B, int L1, int L2, int L3) {
+  if (B <= 0 || L1 <= 0 || L2 <= 0 || L3 <= 0) return 0;
+  const ClsPlan a = make_plan(B, L1, L2, 0), b = make_plan(B, L1, L2, 1);
+  const int64_t fa = plan_scratch_floats(a, B, L1, L2, L3), fb = plan_scratch_floats(b, B, L1, L2, L3);
+  return (fa > fb ? fa : fb) * (int64_t)sizeof(float);
+}
+
+extern "C" int nnue_classifier_forward(const float* x, int pairwise, const float* w1, const float* b1, const float* w2,
+                                       const float* b2, const float* w3, const float* b3, float clip, int B, int L1,
+                                       int L2, int L3, int C, float* h1, float* h2, float* logits, void* scratch,
+                                       int64_t scratch_bytes, nnue_stream_t stream) {
+  NNUE_REQUIRE(x && w1 && b1 && w2 && b2 && w3 && b3 && h1 && h2 && logits && scratch, NNUE_E_ARG,
+               "nnue_classifier_forward: null pointer");
+  NNUE_REQUIRE(B > 0 && L1 > 0 && L2 > 0 && L3 > 0 && C > 0, NNUE_E_ARG,
+               "nnue_classifier_forward: B=%d L1=%d L2=%d L3=%d C=%d must be positive", B, L1, L2, L3, C);
+  NNUE_REQUIRE(!pairwise || L1 % 2 == 0, NNUE_E_SHAPE, "nnue_classifier_forward: pairwise needs an even L1 (got %d)", L1);
+  NNUE_REQUIRE((int64_t)(L2 + L3) * 4 <= 64 * 1024, NNUE_E_SHAPE, "nnue_classifier_forward: L2+L3 too large for the LDS tail");
+  const ClsPlan p = make_plan(B, L1, L2, pairwise);
+  NNUE_REQUIRE(scratch_bytes >= plan_scratch_floats(p, B, L1, L2, L3) * (int64_t)sizeof(float), NNUE_E_SCRATCH,
+               "nnue_classifier_forward: scratch %lld bytes too small", (long long)scratch_bytes);
+  NNUE_REQUIRE(nnue_aligned16(x) && nnue_aligned16(w1) && nnue_aligned16(scratch), NNUE_E_ARG,
+               "nnue_classifier_forward: pointers must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* part = static_cast<float*>(scratch);
+  if (p.fwd_mfma) {
+    const long long waves = (long long)((B + 15) / 16) * ((L2 + 63) / 64) * p.fwd_ksplit;
+    hipLaunchKernelGGL(l1_forward_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, B, L1, L2,
+                       p.fwd_ksplit, part);
+  } else {
+    const long long waves = (long long)B * L2;
+    hipLaunchKernelGGL(l1_forward_simple, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, B, L1, L2, part);
+  }
+  hipLaunchKernelGGL(tail_forward_kernel, dim3(B), dim3(128), (size_t)(L2 + L3) * sizeof(float), s, part, p.fwd_ksplit, b1,
+                     w2, b2, w3, b3, clip, B, L2, L3, C, h1, h2, logits);
+  return nnue_launch_status("nnue_classifier_forward");
+}
+
+extern "C" int nnue_classifier_backward(const float* x, int pairwise, const float* w1, const float* w2, const float* w3,
+                                        float clip, const float* h1, const float* h2, const float* d_logits, int B, int L1,
+                                        int L2, int L3, int C, float* d_x, float* d_w1, float* d_b1, float* d_w2,
+                                        float* d_b2, float* d_w3, float* d_b3, void* scratch, int64_t scratch_bytes,
+                                        nnue_stream_t stream) {
+  NNUE_REQUIRE(x && w1 && w2 && w3 && h1 && h2 && d_logits && scratch, NNUE_E_ARG, "nnue_classifier_backward: null input pointer");
+  NNUE_REQUIRE(d_w1 && d_b1 && d_w2 && d_b2 && d_w3 && d_b3, NNUE_E_ARG, "nnue_classifier_backward: null gradient pointer");
+  NNUE_REQUIRE(B > 0 && L1 > 0 && L2 > 0 && L3 > 0 && C > 0, NNUE_E_ARG,
+               "nnue_classifier_backward: B=%d L1=%d L2=%d L3=%d C=%d must be positive", B, L1, L2, L3, C);
+  NNUE_REQUIRE(!pairwise || L1 % 2 == 0, NNUE_E_SHAPE, "nnue_classifier_backward: pairwise needs an even L1 (got %d)", L1);
+  NNUE_REQUIRE((int64_t)(C + L3) * 4 <= 64 * 1024, NNUE_E_SHAPE, "nnue_classifier_backward: C+L3 too large for the LDS tail");
+  const ClsPlan p = make_plan(B, L1, L2, pairwise);
+  NNUE_REQUIRE(scratch_bytes >= plan_scratch_floats(p, B, L1, L2, L3) * (int64_t)sizeof(float), NNUE_E_SCRATCH,
+               "nnue_classifier_backward: scratch %lld bytes too small", (long long)scratch_bytes);
+  NNUE_REQUIRE(nnue_aligned16(x) && nnue_aligned16(w1) && nnue_aligned16(scratch) && nnue_aligned16(d_w1), NNUE_E_ARG,
+               "nnue_classifier_backward: pointers must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* d_z1 = static_cast<float*>(scratch);
+  float* d_z2 = d_z1 + nnue_round_up((int64_t)B * L2, 4);
+  float* slabs = d_z2 + nnue_round_up((int64_t)B * L3, 4);
+  hipLaunchKernelGGL(tail_backward_kernel, dim3(B), dim3(128), (size_t)(C + L3) * sizeof(float), s, d_logits, h1, h2, w2, w3,
+                     clip, L2, L3, C, d_z1, d_z2);
+  {
+    const long long outs = (long long)C * L3 + C + (long long)L3 * L2 + L3 + L2;
+    hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, s, d_logits, d_z2, d_z1, h1, h2, B,
+                       L2, L3, C, d_w3, d_b3, d_w2, d_b2, d_b1);
+  }
+  if (p.bww_mfma) {
+    const long long waves = (long long)(L2 / 32) * (L1 / 64) * p.bww_ksplit;
+    float* target = p.bww_ksplit > 1 ? slabs : d_w1;
+    hipLaunchKernelGGL(l1_backward_w_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, d_z1, B, L1, L2,
+                       p.bww_ksplit, p.bww_klen, target);
+    if (p.bww_ksplit > 1) {
+      const long long count = (long long)L2 * L1;
+      hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, s, slabs, p.bww_ksplit,
+                         count, d_w1);
+    }
+  } else {
+    hipLaunchKernelGGL(l1_backward_w_simple, dim3(L2, (L1 + 255) / 256), dim3(256), 0, s, x, pairwise, d_z1, B, L1, L2, d_w1);
+  }
+  if (d_x) {
+    if (p.bwx_mfma) {
+      const long long waves = (long long)((B + 15) / 16) * (L1 / 32);
+      hipLaunchKernelGGL(l1_backward_x_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1,
+                         L2, d_x);
+    } else {
+      const int cols = pairwise ? L1 / 2 : L1;
+      hipLaunchKernelGGL(l1_backward_x_simple, dim3(B, (cols + 255) / 256), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1, L2,
+                         d_x);
+    }
+  }
+  return nnue_launch_status("nnue_classifier_backward");
+}

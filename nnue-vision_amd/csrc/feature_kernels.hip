@@ -1,0 +1,268 @@
+// Front end of the NNUE hot path on gfx950: 3x3 conv, straight-through binarisation with
+// active-id compaction, and the backward that reaches the threshold and the conv weight.
+// Reference arithmetic: nnue.py:486-493/:640 (conv), :19-54 (StraightThroughBinary),
+// :590-635 (_to_sparse_features).
+#include "common.h"
+
+namespace {
+
+constexpr float kSteSharpness = 10.0f;  // k, nnue.py:41
+constexpr int kConvChunk = 8;           // output channels per register pass
+
+// ------------------------------------------------------------------ conv forward
+// One thread per output position (b, h, w); the 27-value input patch sits in registers and is
+// reused for every output channel; weights are broadcast from LDS.  Each output is a single
+// fmaf chain over (ci, kh, kw) in that order.
+__global__ __launch_bounds__(256) void conv3x3_forward_kernel(const float* __restrict__ img,
+                                                              const float* __restrict__ w,
+                                                              float* __restrict__ out, int B, int H, int W,
+                                                              int fps, int stride, int Gh, int Gw) {
+  extern __shared__ float w_lds[];  // [fps][27]
+  for (int i = threadIdx.x; i < fps * 27; i += blockDim.x) w_lds[i] = w[i];
+  __syncthreads();
+  const int G = Gh * Gw;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)B * G) return;
+  const int b = (int)(t / G);
+  const int hw = (int)(t - (long long)b * G);
+  const int h = hw / Gw, x = hw - h * Gw;
+  float patch[27];
+#pragma unroll
+  for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iy = h * stride + kh - 1, ix = x * stride + kw - 1;
+        const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        patch[ci * 9 + kh * 3 + kw] = in ? img[(((size_t)b * 3 + ci) * H + iy) * W + ix] : 0.0f;
+      }
+  for (int c0 = 0; c0 < fps; c0 += kConvChunk) {
+    float acc[kConvChunk];
+#pragma unroll
+    for (int u = 0; u < kConvChunk; ++u) acc[u] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 27; ++q)
+#pragma unroll
+      for (int u = 0; u < kConvChunk; ++u) {
+        const int c = (c0 + u < fps) ? c0 + u : fps - 1;  // clamp keeps the LDS read in range
+        acc[u] = fmaf(patch[q], w_lds[c * 27 + q], acc[u]);
+      }
+#pragma unroll
+    for (int u = 0; u < kConvChunk; ++u)
+      if (c0 + u < fps) out[((size_t)b * fps + c0 + u) * G + hw] = acc[u];
+  }
+}
+
+// ------------------------------------------------------------------ binarise + compact
+// One workgroup per sample walks the flat ids p = c*G + hw in ascending order, 256 at a time:
+// bit = conv_out > thr[c]; wave ballots + a 4-entry LDS scan give each active id its slot, so the
+// list comes out ascending (bit-exact ids).  The clamp sink (ids >= F-1 all hit table row F-1,
+// nnue.py:701) is counted here and stored as coefT[F-1, b].
+__global__ __launch_bounds__(256) void binarize_compact_kernel(const float* __restrict__ conv_out,
+                                                               const float* __restrict__ thr, int G, int P, int F,
+                                                               int* __restrict__ rows, int* __restrict__ pos,
+                                                               float* __restrict__ coef, int* __restrict__ n,
+                                                               float* __restrict__ coefT, int ldb) {
+  __shared__ int wave_count[4];
+  __shared__ int sink_count[4];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* __restrict__ x = conv_out + (size_t)b * P;
+  const size_t base = (size_t)b * P;
+  int written = 0, sink = 0;
+  for (int p0 = 0; p0 < P; p0 += 256) {
+    const int p = p0 + tid;
+    const bool on = (p < P) && (x[p] > thr[p / G]);
+    const unsigned long long m = __ballot(on);
+    const unsigned long long ms = __ballot(on && p >= F - 1);
+    if (lane == 0) {
+      wave_count[wave] = __popcll(m);
+      sink_count[wave] = __popcll(ms);
+    }
+    __syncthreads();
+    int offset = written, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int c = wave_count[w];
+      if (w < wave) offset += c;
+      total += c;
+      sink += sink_count[w];
+    }
+    if (on) {
+      const int k = offset + __popcll(m & ((1ull << lane) - 1ull));
+      rows[base + k] = p < F - 1 ? p : F - 1;
+      pos[base + k] = p;
+      coef[base + k] = 1.0f;
+    }
+    written += total;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    n[b] = written;
+    coefT[(size_t)(F - 1) * ldb + b] = (float)sink;
+  }
+}
+
+// coefT rows 0..F-2 as a 64x64 LDS-tiled transpose of the bit map: reads are coalesced along the
+// flat id, writes along the sample.  Rows >= P (table rows the map cannot reach) are zero.
+__global__ __launch_bounds__(256) void binarize_transpose_kernel(const float* __restrict__ conv_out,
+                                                                 const float* __restrict__ thr, int B, int G, int P,
+                                                                 int F, float* __restrict__ coefT, int ldb) {
+  __shared__ float tile[64][65];
+  const int p0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int p = p0 + tx;
+  const float t = (p < P) ? thr[p / G] : 0.0f;
+  for (int j = ty; j < 64; j += 4) {
+    const int b = b0 + j;
+    const bool on = (b < B) && (p < P) && (conv_out[(size_t)b * P + p] > t);
+    tile[j][tx] = on ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 64; j += 4) {
+    const int f = p0 + j;
+    if (f < F - 1 && b0 + tx < ldb) coefT[(size_t)f * ldb + b0 + tx] = tile[tx][j];
+  }
+}
+
+// ------------------------------------------------------------------ STE + conv-weight backward
+// Stage 1: grid (fps, chunks); a block owns channel c and a slice of the batch, every thread
+// accumulates the 27 weight-gradient terms and the threshold term over its positions, then the
+// block reduces (wave shuffles + LDS) to one 28-vector.  Stage 2 sums the chunk vectors in order.
+// d_conv_out is zero at inactive positions (57 % at the CIFAR configs), which are skipped.
+__global__ __launch_bounds__(256) void ste_conv_backward_stage1(const float* __restrict__ img,
+                                                                const float* __restrict__ conv_out,
+                                                                const float* __restrict__ thr,
+                                                                const float* __restrict__ d_conv_out, int B, int H,
+                                                                int W, int fps, int stride, int Gh, int Gw,
+                                                                int samples_per_chunk, float* __restrict__ partial) {
+  __shared__ float red[4][28];
+  const int c = blockIdx.x;
+  const int chunk = blockIdx.y;
+  const int G = Gh * Gw;
+  const int b_lo = chunk * samples_per_chunk;
+  const int b_hi = min(B, b_lo + samples_per_chunk);
+  const float t = thr[c];
+  float acc[28];
+#pragma unroll
+  for (int q = 0; q < 28; ++q) acc[q] = 0.0f;
+  const int work = (b_hi - b_lo) * G;
+  for (int i = threadIdx.x; i < work; i += 256) {
+    const int b = b_lo + i / G;
+    const int hw = i - (i / G) * G;
+    const size_t o = ((size_t)b * fps + c) * G + hw;
+    const float d = d_conv_out[o];
+    if (d == 0.0f) continue;
+    const float s = 1.0f / (1.0f + __expf(-kSteSharpness * (conv_out[o] - t)));
+    acc[27] = fmaf(d, (kSteSharpness * s) * (1.0f - s), acc[27]);
+    const int h = hw / Gw, x = hw - h * Gw;
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int iy = h * stride + kh - 1, ix = x * stride + kw - 1;
+          if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+            acc[ci * 9 + kh * 3 + kw] = fmaf(d, img[(((size_t)b * 3 + ci) * H + iy) * W + ix], acc[ci * 9 + kh * 3 + kw]);
+        }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 28; ++q) {
+    float v = acc[q];
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft);
+    if (lane == 0) red[wave][q] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 28)
+    partial[((size_t)chunk * fps + c) * 28 + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(64) void ste_conv_backward_stage2(const float* __restrict__ partial, int chunks, int fps,
+                                                               float* __restrict__ d_thr, float* __restrict__ d_weight) {
+  const int c = blockIdx.x, q = threadIdx.x;
+  if (q >= 28) return;
+  float acc = 0.0f;
+  for (int k = 0; k < chunks; ++k) acc += partial[((size_t)k * fps + c) * 28 + q];
+  if (q == 27) {
+    if (d_thr) d_thr[c] = -acc;
+  } else if (d_weight) {
+    d_weight[c * 27 + q] = acc;
+  }
+}
+
+int ste_chunks(int B, int fps) {
+  int chunks = 2048 / (fps > 0 ? fps : 1);
+  if (chunks < 1) chunks = 1;
+  if (chunks > B) chunks = B;
+  return chunks;
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" int nnue_conv3x3_forward(const float* images, const float* weight, float* conv_out, int B, int H, int W,
+                                    int fps, int stride, nnue_stream_t stream) {
+  NNUE_REQUIRE(images && weight && conv_out, NNUE_E_ARG, "nnue_conv3x3_forward: null pointer");
+  NNUE_REQUIRE(B > 0 && H > 0 && W > 0 && fps > 0 && stride > 0, NNUE_E_ARG,
+               "nnue_conv3x3_forward: B=%d H=%d W=%d fps=%d stride=%d must be positive", B, H, W, fps, stride);
+  NNUE_REQUIRE(fps * 27 * 4 <= 64 * 1024, NNUE_E_SHAPE, "nnue_conv3x3_forward: fps=%d too large for the LDS weight tile", fps);
+  const int Gh = (H - 1) / stride + 1, Gw = (W - 1) / stride + 1;
+  const long long total = (long long)B * Gh * Gw;
+  NNUE_REQUIRE(total < (1ll << 31) * 256, NNUE_E_SHAPE, "nnue_conv3x3_forward: too many outputs");
+  hipLaunchKernelGGL(conv3x3_forward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), fps * 27 * sizeof(float),
+                     static_cast<hipStream_t>(stream), images, weight, conv_out, B, H, W, fps, stride, Gh, Gw);
+  return nnue_launch_status("nnue_conv3x3_forward");
+}
+
+extern "C" int nnue_binarize_features(const float* conv_out, const float* thr, int B, int fps, int Gh, int Gw, int F,
+                                      int32_t* rows, int32_t* pos, float* coef, int32_t* n, float* coefT, int ldb,
+                                      nnue_stream_t stream) {
+  NNUE_REQUIRE(conv_out && thr && rows && pos && coef && n && coefT, NNUE_E_ARG, "nnue_binarize_features: null pointer");
+  NNUE_REQUIRE(B > 0 && fps > 0 && Gh > 0 && Gw > 0 && F > 0, NNUE_E_ARG,
+               "nnue_binarize_features: B=%d fps=%d Gh=%d Gw=%d F=%d must be positive", B, fps, Gh, Gw, F);
+  NNUE_REQUIRE(ldb >= B && ldb % 64 == 0, NNUE_E_SHAPE, "nnue_binarize_features: ldb=%d must be a multiple of 64 and >= B=%d", ldb, B);
+  const long long P64 = (long long)fps * Gh * Gw;
+  NNUE_REQUIRE(P64 < (1ll << 30), NNUE_E_SHAPE, "nnue_binarize_features: fps*Gh*Gw too large");
+  const int P = (int)P64, G = Gh * Gw;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (F > 1)
+    hipLaunchKernelGGL(binarize_transpose_kernel, dim3((F - 1 + 63) / 64, ldb / 64), dim3(256), 0, s, conv_out, thr, B, G,
+                       P, F, coefT, ldb);
+  hipLaunchKernelGGL(binarize_compact_kernel, dim3(B), dim3(256), 0, s, conv_out, thr, G, P, F, rows, pos, coef, n, coefT,
+                     ldb);
+  return nnue_launch_status("nnue_binarize_features");
+}
+
+extern "C" int64_t nnue_ste_conv_backward_scratch(int B, int fps, int Gh, int Gw) {
+  (void)Gh;
+  (void)Gw;
+  if (B <= 0 || fps <= 0) return 0;
+  return (int64_t)ste_chunks(B, fps) * fps * 28 * sizeof(float);
+}
+
+extern "C" int nnue_ste_conv_backward(const float* images, const float* conv_out, const float* thr,
+                                      const float* d_conv_out, int B, int H, int W, int fps, int stride, float* d_thr,
+                                      float* d_weight, void* scratch, int64_t scratch_bytes, nnue_stream_t stream) {
+  NNUE_REQUIRE(images && conv_out && thr && d_conv_out && scratch, NNUE_E_ARG, "nnue_ste_conv_backward: null pointer");
+  NNUE_REQUIRE(d_thr || d_weight, NNUE_E_ARG, "nnue_ste_conv_backward: both outputs are null");
+  NNUE_REQUIRE(B > 0 && H > 0 && W > 0 && fps > 0 && stride > 0, NNUE_E_ARG,
+               "nnue_ste_conv_backward: B=%d H=%d W=%d fps=%d stride=%d must be positive", B, H, W, fps, stride);
+  const int Gh = (H - 1) / stride + 1, Gw = (W - 1) / stride + 1;
+  NNUE_REQUIRE(scratch_bytes >= nnue_ste_conv_backward_scratch(B, fps, Gh, Gw), NNUE_E_SCRATCH,
+               "nnue_ste_conv_backward: scratch %lld < %lld bytes", (long long)scratch_bytes,
+               (long long)nnue_ste_conv_backward_scratch(B, fps, Gh, Gw));
+  const int chunks = ste_chunks(B, fps);
+  const int spc = (B + chunks - 1) / chunks;
+  NNUE_REQUIRE((long long)spc * Gh * Gw < (1ll << 31), NNUE_E_SHAPE, "nnue_ste_conv_backward: chunk too large");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* partial = static_cast<float*>(scratch);
+  hipLaunchKernelGGL(ste_conv_backward_stage1, dim3(fps, chunks), dim3(256), 0, s, images, conv_out, thr, d_conv_out, B, H,
+                     W, fps, stride, Gh, Gw, spc, partial);
+  hipLaunchKernelGGL(ste_conv_backward_stage2, dim3(fps), dim3(64), 0, s, partial, chunks, fps, d_thr, d_weight);
+  return nnue_launch_status("nnue_ste_conv_backward");
+}

@@ -1,0 +1,148 @@
+// Loss and step tail on gfx950: mean cross-entropy with its gradient (train.py:250-254) and
+// clip_grad_norm_ + SGD(momentum, weight_decay) on one flat buffer (train.py:363-366, :457-464).
+// Both are small streaming kernels; sums are staged so results are bitwise reproducible.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) v = fmaxf(v, __shfl_xor(v, s));
+  return v;
+}
+
+// one wave per sample
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ logits,
+                                                            const int64_t* __restrict__ labels, int B, int C,
+                                                            float scale_over_b, float* __restrict__ sample_loss,
+                                                            float* __restrict__ d_logits) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= B) return;
+  const float* __restrict__ z = logits + (size_t)b * C;
+  float mx = -INFINITY;
+  for (int c = lane; c < C; c += 64) mx = fmaxf(mx, z[c]);
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int c = lane; c < C; c += 64) se += expf(z[c] - mx);
+  se = wave_sum(se);
+  const int64_t y = labels[b];
+  const bool ok = y >= 0 && y < C;
+  const float lse = mx + logf(se);
+  if (lane == 0) sample_loss[b] = ok ? lse - z[y] : 0.0f;
+  if (d_logits) {
+    const float inv = 1.0f / se;
+    for (int c = lane; c < C; c += 64) {
+      const float p = expf(z[c] - mx) * inv;
+      d_logits[(size_t)b * C + c] = ok ? (p - (c == y ? 1.0f : 0.0f)) * scale_over_b : 0.0f;
+    }
+  }
+}
+
+// single block: fixed-order mean of the per-sample losses
+__global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += v[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
+}
+
+constexpr int kNormBlocks = 512;
+
+__global__ __launch_bounds__(256) void sqnorm_stage1(const float* __restrict__ g, int64_t count, float scale,
+                                                     float* __restrict__ partial) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+    const float v = g[i] * scale;
+    acc = fmaf(v, v, acc);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Every block re-derives the norm from the kNormBlocks partials (2 KiB, L2-resident) in the same
+// fixed order, then streams its share of the update.
+__global__ __launch_bounds__(256) void sgd_apply_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, int64_t count, float lr, float momentum,
+                                                        float wd, float max_norm, float scale, int first_step,
+                                                        const float* __restrict__ partial, int nparts,
+                                                        float* __restrict__ norm_out) {
+  __shared__ double red[4];
+  __shared__ float coef_s;
+  float clip = 1.0f;
+  if (max_norm > 0.0f || norm_out) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += (double)partial[i];
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float norm = (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
+      if (norm_out && blockIdx.x == 0) *norm_out = norm;
+      coef_s = max_norm > 0.0f ? fminf(max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+    }
+    __syncthreads();
+    clip = coef_s;
+  }
+  const float gs = clip * scale;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+    const float w = p[i];
+    float gi = fmaf(wd, w, g[i] * gs);
+    if (m) {
+      gi = first_step ? gi : fmaf(momentum, m[i], gi);
+      m[i] = gi;
+    }
+    p[i] = w - lr * gi;
+  }
+}
+
+}  // namespace
+
+extern "C" int nnue_cross_entropy(const float* logits, const int64_t* labels, int B, int C, float grad_scale,
+                                  float* sample_loss, float* loss, float* d_logits, nnue_stream_t stream) {
+  NNUE_REQUIRE(logits && labels && sample_loss && loss, NNUE_E_ARG, "nnue_cross_entropy: null pointer");
+  NNUE_REQUIRE(B > 0 && C > 0, NNUE_E_ARG, "nnue_cross_entropy: B=%d C=%d must be positive", B, C);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3((B + 3) / 4), dim3(256), 0, s, logits, labels, B, C,
+                     grad_scale / (float)B, sample_loss, d_logits);
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, sample_loss, B, loss);
+  return nnue_launch_status("nnue_cross_entropy");
+}
+
+extern "C" int64_t nnue_sgd_scratch(int64_t count) {
+  (void)count;
+  return kNormBlocks * (int64_t)sizeof(float);
+}
+
+extern "C" int nnue_sgd_step(float* params, float* grads, float* momentum_buf, int64_t count, float lr, float momentum,
+                             float weight_decay, float max_norm, float grad_scale, int first_step, float* norm_out,
+                             void* scratch, int64_t scratch_bytes, nnue_stream_t stream) {
+  NNUE_REQUIRE(params && grads && scratch, NNUE_E_ARG, "nnue_sgd_step: null pointer");
+  NNUE_REQUIRE(count > 0, NNUE_E_ARG, "nnue_sgd_step: count must be positive");
+  NNUE_REQUIRE(momentum == 0.0f || momentum_buf, NNUE_E_ARG, "nnue_sgd_step: momentum %g needs a momentum buffer", momentum);
+  NNUE_REQUIRE(scratch_bytes >= nnue_sgd_scratch(count), NNUE_E_SCRATCH, "nnue_sgd_step: scratch %lld < %lld bytes",
+               (long long)scratch_bytes, (long long)nnue_sgd_scratch(count));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* partial = static_cast<float*>(scratch);
+  if (max_norm > 0.0f || norm_out)
+    hipLaunchKernelGGL(sqnorm_stage1, dim3(kNormBlocks), dim3(256), 0, s, grads, count, grad_scale, partial);
+  int blocks = (int)((count + 1023) / 1024);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(sgd_apply_kernel, dim3(blocks), dim3(256), 0, s, params, grads, momentum == 0.0f ? nullptr : momentum_buf,
+                     count, lr, momentum, weight_decay, max_norm, grad_scale, first_step, partial, kNormBlocks, norm_out);
+  return nnue_launch_status("nnue_sgd_step");
+}

@@ -1,0 +1,361 @@
+"""ctypes binding of libnnue_hip.so (C ABI: include/nnue_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every wrapper checks
+device / dtype / contiguity / shapes on the host, then passes raw pointers.  There is no
+fallback of any kind: if the library is missing or a tensor is not on the GPU the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Optional, Tuple
+
+import torch
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libnnue_hip.so"
+ABI_VERSION = 1
+
+_c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/nnue_hip.h one to one
+SIGNATURES = {
+    "nnue_hip_abi_version": (_c_int, []),
+    "nnue_hip_last_error": (ctypes.c_char_p, []),
+    "nnue_conv3x3_forward": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    "nnue_binarize_features": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                        _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_p]),
+    "nnue_act_to_padded": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
+    "nnue_ste_conv_backward_scratch": (_c_i64, [_c_int, _c_int, _c_int, _c_int]),
+    "nnue_ste_conv_backward": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                        _c_p, _c_p, _c_p, _c_i64, _c_p]),
+    "nnue_ft_prepare": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_p]),
+    "nnue_ft_forward": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p]),
+    "nnue_ft_backward_weight": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
+    "nnue_ft_backward_values": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int,
+                                         _c_p, _c_int, _c_p]),
+    "nnue_classifier_scratch": (_c_i64, [_c_int, _c_int, _c_int, _c_int]),
+    "nnue_classifier_forward": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_f,
+                                         _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p,
+                                         _c_p, _c_i64, _c_p]),
+    "nnue_classifier_backward": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p, _c_f, _c_p, _c_p, _c_p,
+                                          _c_int, _c_int, _c_int, _c_int, _c_int,
+                                          _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
+    "nnue_cross_entropy": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_f, _c_p, _c_p, _c_p, _c_p]),
+    "nnue_sgd_scratch": (_c_i64, [_c_i64]),
+    "nnue_sgd_step": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_int,
+                               _c_p, _c_p, _c_i64, _c_p]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class NnueHipError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Loads the library (once).  Raises loudly if it was not built -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise NnueHipError(
+            f"{LIB_PATH} is missing: build it with `python nnue-vision_amd/csrc/build.py` "
+            "(or __graft_entry__.build()).  There is no CPU or eager fallback.")
+    lib = ctypes.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    got = lib.nnue_hip_abi_version()
+    if got != ABI_VERSION:
+        raise NnueHipError(f"libnnue_hip.so ABI {got} != binding ABI {ABI_VERSION}: rebuild")
+    _lib = lib
+    return lib
+
+
+def _call(name: str, *args) -> None:
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise NnueHipError(f"{name} failed (code {rc}): {lib.nnue_hip_last_error().decode()}")
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _need(t: torch.Tensor, dtype, what: str, shape: Optional[Tuple[int, ...]] = None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{what}: expected a tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise NnueHipError(f"{what}: tensor is on {t.device}; the NNUE hot path runs on the GPU only "
+                           "(no CPU fallback in this build)")
+    if t.dtype != dtype:
+        raise TypeError(f"{what}: expected {dtype}, got {t.dtype}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{what}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+@dataclass
+class ActList:
+    """Active-feature list + transposed coefficients (layout: include/nnue_hip.h)."""
+    rows: torch.Tensor   # int32 [B, cap]
+    pos: torch.Tensor    # int32 [B, cap]
+    coef: torch.Tensor   # float32 [B, cap]
+    n: torch.Tensor      # int32 [B]
+    coefT: torch.Tensor  # float32 [F, ldb]
+    cap: int
+    ldb: int
+
+    @property
+    def batch(self) -> int:
+        return self.n.shape[0]
+
+    @staticmethod
+    def empty(batch: int, cap: int, num_rows: int, device) -> "ActList":
+        ldb = round_up(batch, 64)
+        i32 = dict(dtype=torch.int32, device=device)
+        return ActList(torch.empty((batch, cap), **i32), torch.empty((batch, cap), **i32),
+                       torch.empty((batch, cap), dtype=torch.float32, device=device),
+                       torch.empty((batch,), **i32),
+                       torch.empty((num_rows, ldb), dtype=torch.float32, device=device), cap, ldb)
+
+
+# ---------------------------------------------------------------------------- front end
+def conv_out_hw(h: int, w: int, stride: int) -> Tuple[int, int]:
+    return (h - 1) // stride + 1, (w - 1) // stride + 1
+
+
+def conv3x3_forward(images: torch.Tensor, weight: torch.Tensor, stride: int,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if images.dim() != 4 or images.shape[1] != 3:
+        raise ValueError(f"images: expected [B,3,H,W], got {tuple(images.shape)}")
+    images = _need(images, torch.float32, "images")
+    b, _, h, w = images.shape
+    fps = weight.shape[0]
+    weight = _need(weight, torch.float32, "conv weight", (fps, 3, 3, 3))
+    gh, gw = conv_out_hw(h, w, stride)
+    if out is None:
+        out = torch.empty((b, fps, gh, gw), dtype=torch.float32, device=images.device)
+    else:
+        _need(out, torch.float32, "conv_out", (b, fps, gh, gw))
+    _call("nnue_conv3x3_forward", images.data_ptr(), weight.data_ptr(), out.data_ptr(), b, h, w, fps, stride,
+          _stream(images))
+    return out
+
+
+def binarize_features(conv_out: torch.Tensor, thr: torch.Tensor, num_rows: int,
+                      act: Optional[ActList] = None) -> ActList:
+    conv_out = _need(conv_out, torch.float32, "conv_out")
+    if conv_out.dim() != 4:
+        raise ValueError(f"conv_out: expected [B,fps,Gh,Gw], got {tuple(conv_out.shape)}")
+    b, fps, gh, gw = conv_out.shape
+    thr = _need(thr.reshape(-1), torch.float32, "threshold", (fps,))
+    cap = fps * gh * gw
+    if act is None:
+        act = ActList.empty(b, cap, num_rows, conv_out.device)
+    elif act.cap != cap or act.batch != b or act.coefT.shape != (num_rows, act.ldb):
+        raise ValueError("binarize_features: act list does not match the map")
+    _call("nnue_binarize_features", conv_out.data_ptr(), thr.data_ptr(), b, fps, gh, gw, num_rows,
+          act.rows.data_ptr(), act.pos.data_ptr(), act.coef.data_ptr(), act.n.data_ptr(),
+          act.coefT.data_ptr(), act.ldb, _stream(conv_out))
+    return act
+
+
+def act_to_padded(act: ActList, width: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    b = act.batch
+    idx = torch.empty((b, width), dtype=torch.int64, device=act.n.device)
+    val = torch.empty((b, width), dtype=torch.float32, device=act.n.device)
+    _call("nnue_act_to_padded", act.pos.data_ptr(), act.coef.data_ptr(), act.n.data_ptr(), act.cap, b, width,
+          idx.data_ptr(), val.data_ptr(), _stream(act.n))
+    return idx, val
+
+
+def ste_conv_backward(images, conv_out, thr, d_conv_out, stride: int,
+                      d_thr: Optional[torch.Tensor] = None, d_weight: Optional[torch.Tensor] = None,
+                      scratch: Optional[torch.Tensor] = None):
+    images = _need(images, torch.float32, "images")
+    b, _, h, w = images.shape
+    fps = conv_out.shape[1]
+    gh, gw = conv_out_hw(h, w, stride)
+    conv_out = _need(conv_out, torch.float32, "conv_out", (b, fps, gh, gw))
+    d_conv_out = _need(d_conv_out, torch.float32, "d_conv_out").view(b, fps, gh, gw)
+    thr = _need(thr.reshape(-1), torch.float32, "threshold", (fps,))
+    dev = images.device
+    if d_thr is None:
+        d_thr = torch.empty((fps,), dtype=torch.float32, device=dev)
+    if d_weight is None:
+        d_weight = torch.empty((fps, 3, 3, 3), dtype=torch.float32, device=dev)
+    need = load().nnue_ste_conv_backward_scratch(b, fps, gh, gw)
+    if scratch is None:
+        scratch = torch.empty((need,), dtype=torch.uint8, device=dev)
+    _call("nnue_ste_conv_backward", images.data_ptr(), conv_out.data_ptr(), thr.data_ptr(), d_conv_out.data_ptr(),
+          b, h, w, fps, stride, d_thr.data_ptr(), d_weight.data_ptr(), scratch.data_ptr(), scratch.numel(),
+          _stream(images))
+    return d_thr, d_weight
+
+
+# ---------------------------------------------------------------------------- FeatureTransformer
+def ft_prepare(idx: torch.Tensor, val: torch.Tensor, num_rows: int) -> ActList:
+    if idx.dim() != 2 or idx.shape != val.shape:
+        raise ValueError(f"feature_indices / feature_values: expected matching [B,M], got "
+                         f"{tuple(idx.shape)} and {tuple(val.shape)}")
+    idx = _need(idx, torch.int64, "feature_indices")
+    val = _need(val, torch.float32, "feature_values")
+    b, m = idx.shape
+    act = ActList.empty(b, m, num_rows, idx.device)
+    _call("nnue_ft_prepare", idx.data_ptr(), val.data_ptr(), b, m, num_rows, act.rows.data_ptr(), act.pos.data_ptr(),
+          act.coef.data_ptr(), act.n.data_ptr(), act.coefT.data_ptr(), act.ldb, _stream(idx))
+    return act
+
+
+def ft_forward(weight: torch.Tensor, bias: torch.Tensor, act: ActList,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    weight = _need(weight, torch.float32, "input.weight")
+    f, l1 = weight.shape
+    bias = _need(bias, torch.float32, "input.bias", (l1,))
+    if act.coefT.shape[0] != f:
+        raise ValueError("ft_forward: act list was built for a different table")
+    if out is None:
+        out = torch.empty((act.batch, l1), dtype=torch.float32, device=weight.device)
+    _call("nnue_ft_forward", weight.data_ptr(), bias.data_ptr(), act.rows.data_ptr(), act.coef.data_ptr(),
+          act.n.data_ptr(), act.cap, act.batch, f, l1, out.data_ptr(), _stream(weight))
+    return out
+
+
+def ft_backward_weight(d_out: torch.Tensor, act: ActList, num_rows: int,
+                       d_weight: Optional[torch.Tensor] = None, d_bias: Optional[torch.Tensor] = None,
+                       want_weight: bool = True, want_bias: bool = True):
+    d_out = _need(d_out, torch.float32, "d_out")
+    b, l1 = d_out.shape
+    if b != act.batch or act.coefT.shape[0] != num_rows:
+        raise ValueError("ft_backward_weight: act list does not match d_out / table")
+    if want_weight and d_weight is None:
+        d_weight = torch.empty((num_rows, l1), dtype=torch.float32, device=d_out.device)
+    if want_bias and d_bias is None:
+        d_bias = torch.empty((l1,), dtype=torch.float32, device=d_out.device)
+    _call("nnue_ft_backward_weight", d_out.data_ptr(), act.coefT.data_ptr(), act.ldb, b, num_rows, l1,
+          _ptr(d_weight if want_weight else None), _ptr(d_bias if want_bias else None), _stream(d_out))
+    return d_weight, d_bias
+
+
+def ft_backward_values(d_out: torch.Tensor, weight: torch.Tensor, act: ActList, dst_ld: int,
+                       dst: Optional[torch.Tensor] = None) -> torch.Tensor:
+    d_out = _need(d_out, torch.float32, "d_out")
+    weight = _need(weight, torch.float32, "input.weight")
+    b, l1 = d_out.shape
+    f = weight.shape[0]
+    if weight.shape[1] != l1 or b != act.batch:
+        raise ValueError("ft_backward_values: shape mismatch")
+    if dst is None:
+        dst = torch.empty((b, dst_ld), dtype=torch.float32, device=d_out.device)
+    elif dst.numel() != b * dst_ld:
+        raise ValueError("ft_backward_values: dst has the wrong size")
+    _call("nnue_ft_backward_values", d_out.data_ptr(), weight.data_ptr(), act.rows.data_ptr(), act.pos.data_ptr(),
+          act.n.data_ptr(), act.cap, b, f, l1, dst.data_ptr(), dst_ld, _stream(d_out))
+    return dst
+
+
+# ---------------------------------------------------------------------------- classifier
+def classifier_scratch_bytes(b: int, l1: int, l2: int, l3: int) -> int:
+    return int(load().nnue_classifier_scratch(b, l1, l2, l3))
+
+
+def classifier_forward(x, pairwise: bool, w1, b1, w2, b2, w3, b3, clip: float = 0.0,
+                       scratch: Optional[torch.Tensor] = None, out=None):
+    x = _need(x, torch.float32, "classifier input")
+    if x.dim() != 2:
+        raise ValueError(f"classifier input: expected [B,L1], got {tuple(x.shape)}")
+    b, l1 = x.shape
+    l2, l3, c = w1.shape[0], w2.shape[0], w3.shape[0]
+    w1 = _need(w1, torch.float32, "classifier.0.weight", (l2, l1))
+    b1 = _need(b1, torch.float32, "classifier.0.bias", (l2,))
+    w2 = _need(w2, torch.float32, "classifier.2.weight", (l3, l2))
+    b2 = _need(b2, torch.float32, "classifier.2.bias", (l3,))
+    w3 = _need(w3, torch.float32, "classifier.4.weight", (c, l3))
+    b3 = _need(b3, torch.float32, "classifier.4.bias", (c,))
+    dev = x.device
+    if scratch is None:
+        scratch = torch.empty((classifier_scratch_bytes(b, l1, l2, l3),), dtype=torch.uint8, device=dev)
+    if out is None:
+        h1 = torch.empty((b, l2), dtype=torch.float32, device=dev)
+        h2 = torch.empty((b, l3), dtype=torch.float32, device=dev)
+        logits = torch.empty((b, c), dtype=torch.float32, device=dev)
+    else:
+        h1, h2, logits = out
+    _call("nnue_classifier_forward", x.data_ptr(), int(bool(pairwise)), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+          b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), float(clip), b, l1, l2, l3, c, h1.data_ptr(), h2.data_ptr(),
+          logits.data_ptr(), scratch.data_ptr(), scratch.numel(), _stream(x))
+    return h1, h2, logits
+
+
+def classifier_backward(x, pairwise: bool, w1, w2, w3, h1, h2, d_logits, clip: float = 0.0,
+                        want_dx: bool = True, scratch: Optional[torch.Tensor] = None, grads=None, d_x=None):
+    x = _need(x, torch.float32, "classifier input")
+    b, l1 = x.shape
+    l2, l3, c = w1.shape[0], w2.shape[0], w3.shape[0]
+    w1 = _need(w1, torch.float32, "classifier.0.weight", (l2, l1))
+    w2 = _need(w2, torch.float32, "classifier.2.weight", (l3, l2))
+    w3 = _need(w3, torch.float32, "classifier.4.weight", (c, l3))
+    h1 = _need(h1, torch.float32, "h1", (b, l2))
+    h2 = _need(h2, torch.float32, "h2", (b, l3))
+    d_logits = _need(d_logits, torch.float32, "d_logits", (b, c))
+    dev = x.device
+    if scratch is None:
+        scratch = torch.empty((classifier_scratch_bytes(b, l1, l2, l3),), dtype=torch.uint8, device=dev)
+    if grads is None:
+        mk = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+        grads = (mk(l2, l1), mk(l2), mk(l3, l2), mk(l3), mk(c, l3), mk(c))
+    if want_dx and d_x is None:
+        d_x = torch.empty((b, l1), dtype=torch.float32, device=dev)
+    _call("nnue_classifier_backward", x.data_ptr(), int(bool(pairwise)), w1.data_ptr(), w2.data_ptr(), w3.data_ptr(),
+          float(clip), h1.data_ptr(), h2.data_ptr(), d_logits.data_ptr(), b, l1, l2, l3, c,
+          _ptr(d_x if want_dx else None), *[g.data_ptr() for g in grads], scratch.data_ptr(), scratch.numel(),
+          _stream(x))
+    return (d_x if want_dx else None), grads
+
+
+# ---------------------------------------------------------------------------- loss + step tail
+def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, grad_scale: float = 1.0, want_grad: bool = True,
+                  out=None):
+    logits = _need(logits, torch.float32, "logits")
+    b, c = logits.shape
+    labels = _need(labels, torch.int64, "labels", (b,))
+    dev = logits.device
+    if out is None:
+        sample_loss = torch.empty((b,), dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        d_logits = torch.empty((b, c), dtype=torch.float32, device=dev) if want_grad else None
+    else:
+        sample_loss, loss, d_logits = out
+    _call("nnue_cross_entropy", logits.data_ptr(), labels.data_ptr(), b, c, float(grad_scale), sample_loss.data_ptr(),
+          loss.data_ptr(), _ptr(d_logits), _stream(logits))
+    return sample_loss, loss, d_logits
+
+
+def sgd_scratch_bytes(count: int) -> int:
+    return int(load().nnue_sgd_scratch(count))
+
+
+def sgd_step(params: torch.Tensor, grads: torch.Tensor, momentum_buf: Optional[torch.Tensor], lr: float,
+             momentum: float, weight_decay: float, max_norm: float, grad_scale: float, first_step: bool,
+             norm_out: Optional[torch.Tensor], scratch: torch.Tensor) -> None:
+    params = _need(params, torch.float32, "flat params")
+    grads = _need(grads, torch.float32, "flat grads", tuple(params.shape))
+    if momentum_buf is not None:
+        _need(momentum_buf, torch.float32, "momentum buffer", tuple(params.shape))
+    _call("nnue_sgd_step", params.data_ptr(), grads.data_ptr(), _ptr(momentum_buf), params.numel(), float(lr),
+          float(momentum), float(weight_decay), float(max_norm), float(grad_scale), int(bool(first_step)),
+          _ptr(norm_out), scratch.data_ptr(), scratch.numel(), _stream(params))

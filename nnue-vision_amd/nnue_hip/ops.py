@@ -1,0 +1,90 @@
+"""autograd bridges between the nn.Module surface (nnue.py) and the HIP kernels.
+
+Three nodes, each a hand-written forward/backward pair over the C ABI:
+
+* ``FeatureTransformerFn``  -- FeatureTransformer.forward called stand-alone (nnue.py:686-710)
+* ``ClassifierFn``          -- SimpleClassifier.forward called stand-alone (nnue.py:736-738)
+* ``NnueFn``                -- the whole NNUE.forward (nnue.py:637-671) as ONE node: conv, binarise +
+                               compact, gather-accumulate, pairwise + classifier.  No data-dependent
+                               shapes, no host synchronisation.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import lib
+
+
+class FeatureTransformerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, idx, val, weight, bias):
+        act = lib.ft_prepare(idx, val, weight.shape[0])
+        out = lib.ft_forward(weight, bias, act)
+        ctx.act = act
+        ctx.width = idx.shape[1]
+        ctx.save_for_backward(weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (weight,) = ctx.saved_tensors
+        _, need_val, need_w, need_b = ctx.needs_input_grad
+        d_out = d_out.contiguous()
+        d_val = d_w = d_b = None
+        if need_val:
+            d_val = lib.ft_backward_values(d_out, weight, ctx.act, ctx.width)
+        if need_w or need_b:
+            d_w, d_b = lib.ft_backward_weight(d_out, ctx.act, weight.shape[0], want_weight=need_w, want_bias=need_b)
+        return None, d_val, d_w, d_b
+
+
+class ClassifierFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, pairwise, clip):
+        x = x.contiguous()
+        h1, h2, logits = lib.classifier_forward(x, pairwise, w1, b1, w2, b2, w3, b3, clip)
+        ctx.pairwise, ctx.clip = pairwise, clip
+        ctx.save_for_backward(x, w1, w2, w3, h1, h2)
+        return logits
+
+    @staticmethod
+    def backward(ctx, d_logits):
+        x, w1, w2, w3, h1, h2 = ctx.saved_tensors
+        d_x, g = lib.classifier_backward(x, ctx.pairwise, w1, w2, w3, h1, h2, d_logits.contiguous(), ctx.clip,
+                                         want_dx=ctx.needs_input_grad[0])
+        return (d_x, *g, None, None)
+
+
+class NnueFn(torch.autograd.Function):
+    """images -> logits.  Inputs: images, threshold [fps], conv weight, FT weight/bias, 3x (weight, bias)."""
+
+    @staticmethod
+    def forward(ctx, images, thr, conv_w, ft_w, ft_b, w1, b1, w2, b2, w3, b3, stride, clip):
+        images = images.contiguous()
+        conv_out = lib.conv3x3_forward(images, conv_w, stride)
+        act = lib.binarize_features(conv_out, thr, ft_w.shape[0])
+        ft = lib.ft_forward(ft_w, ft_b, act)
+        h1, h2, logits = lib.classifier_forward(ft, True, w1, b1, w2, b2, w3, b3, clip)
+        ctx.act, ctx.stride, ctx.clip = act, stride, clip
+        ctx.save_for_backward(images, thr, conv_w, conv_out, ft_w, ft, w1, w2, w3, h1, h2)
+        return logits
+
+    @staticmethod
+    def backward(ctx, d_logits):
+        images, thr, conv_w, conv_out, ft_w, ft, w1, w2, w3, h1, h2 = ctx.saved_tensors
+        act = ctx.act
+        need = ctx.needs_input_grad
+        d_ft, g_cls = lib.classifier_backward(ft, True, w1, w2, w3, h1, h2, d_logits.contiguous(), ctx.clip)
+        d_ftw = d_ftb = d_thr = d_conv_w = d_images = None
+        if need[3] or need[4]:
+            d_ftw, d_ftb = lib.ft_backward_weight(d_ft, act, ft_w.shape[0], want_weight=need[3], want_bias=need[4])
+        if need[0] or need[1] or need[2]:
+            # value gradient of the binary features == d(conv_out) (identity STE, nnue.py:33)
+            d_conv_out = lib.ft_backward_values(d_ft, ft_w, act, act.cap).view_as(conv_out)
+            if need[1] or need[2]:
+                d_thr, d_conv_w = lib.ste_conv_backward(images, conv_out, thr, d_conv_out, ctx.stride)
+                d_thr = d_thr.view_as(thr)
+            if need[0]:
+                # gradient to the pixels: never needed by the training loop; stock transposed conv
+                d_images = torch.nn.grad.conv2d_input(images.shape, conv_w, d_conv_out, stride=ctx.stride, padding=1)
+        return (d_images, d_thr, d_conv_w, d_ftw, d_ftb, *g_cls, None, None)
