@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""NNUE training throughput on MI355X  (metric: BASELINE.json -- images/sec of the full training step).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3|c4]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
+conv -> binarise/compact -> FeatureTransformer gather-accumulate -> pairwise + classifier -> cross-entropy
+-> full backward -> (all-reduce of the flat gradient when N > 1) -> clip_grad_norm_ + SGD, i.e. what
+train.py:359-366 does per batch.  Default workload = BASELINE configs[1]: CIFAR-10 shapes, batch 512 per
+GPU, 800 -> 1024/128/32 -> 10, fp32, SGD(lr 0.01, momentum 0.9, wd 2e-4), clip 1.0 (config/train_nnue.py).
+Weak scaling: every GPU keeps batch 512 (N=8 is BASELINE configs[4], global batch 4096).
+
+Rank 0 prints ONE JSON line.  Beyond the contract fields it carries
+  roofline      dominant kernel: algorithmic bytes per launch (one gathered / accumulated table
+                row = L1*4 bytes) / its average duration, measured here with HIP events on the launch
+                stream in an instrumented pass that follows the timed region (same buffers, same process);
+  kernels       the same figure for every C entry point of the step;
+  cpu_baseline  the oracle's loop-form port of the reference CPU path (N=1 only) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / "nnue-vision_amd"))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WORKLOADS = {
+    # name: grid, fps, image, l1, l2, l3, classes, per-GPU batch            
+    "c1": dict(grid=10, fps=8, image=32, l1=64, l2=32, l3=8, classes=10, batch=32),
+    "c2": dict(grid=10, fps=8, image=32, l1=1024, l2=128, l3=32, classes=10, batch=512),
+    "c3": dict(grid=10, fps=8, image=32, l1=1024, l2=128, l3=32, classes=100, batch=1024),  # K=1: buckets do not exist in the reference
+    "c4": dict(grid=32, fps=64, image=224, l1=1024, l2=128, l3=32, classes=1000, batch=128),
+}
+OPT = dict(lr=0.01, momentum=0.9, weight_decay=2e-4, max_grad_norm=1.0)  # config/train_nnue.py:29-36
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, budget_s):
+    """Loop-form port of the reference CPU path (oracle/nnue_oracle.py) on the host cores: full steps
+    (forward, backward, clip, SGD) on the same synthetic shapes; bounded by `budget_s`."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import nnue_oracle as orc
+    cores = min(os.cpu_count() or 1, 16)  # the box's CPU share for one GPU
+    torch.set_num_threads(cores)
+    stride = orc.conv_stride(cfg["image"], cfg["grid"])
+    params = orc.init_params(cfg["grid"], cfg["fps"], cfg["l1"], cfg["l2"], cfg["l3"], cfg["classes"], 0)
+    gen = torch.Generator().manual_seed(1234)
+    batch = cfg["batch"]
+    images = torch.randn(batch, 3, cfg["image"], cfg["image"], generator=gen)
+    labels = torch.randint(0, cfg["classes"], (batch,), generator=gen)
+    bufs = {}
+
+    def one():
+        _, _, grads, _ = orc.loss_and_grads_loop(params, images, labels, stride)
+        orc.sgd_step(params, grads, bufs, OPT["lr"], OPT["momentum"], OPT["weight_decay"], OPT["max_grad_norm"])
+
+    t0 = time.perf_counter()
+    one()  # warm-up, also sizes the sample
+    first = time.perf_counter() - t0
+    steps = max(1, min(20, int(budget_s / max(first, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * steps / dt, 1), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{steps} full training steps of batch {batch} after 1 warm-up ({dt:.1f} s), "
+                      f"oracle loop form (per-sample Python loops + autograd, as nnue.py:601-633/:694-708), torch CPU fp32"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    import nnue
+    from nnue_hip.trainer import NnueTrainer
+
+    cfg = WORKLOADS[args.workload]
+    torch.manual_seed(0)
+    model = nnue.NNUE(nnue.GridFeatureSet(cfg["grid"], cfg["fps"]), cfg["l1"], cfg["l2"], cfg["l3"],
+                      num_classes=cfg["classes"], input_size=cfg["image"]).to(dev)
+    B = cfg["batch"]
+    SLOTS = 4
+    trainer = NnueTrainer(model, B, (cfg["image"], cfg["image"]), group=None, use_graph=not args.no_graph,
+                          input_slots=SLOTS, **OPT)
+
+    # synthetic batches, resident in HBM (the trainer's input ring) before the clock starts; every rank
+    # draws its own.  Steps rotate over the slots, so consecutive steps see different data.
+    gen = torch.Generator().manual_seed(1234 + rank)
+    for images, labels in trainer.inputs:
+        images.copy_(torch.randn(B, 3, cfg["image"], cfg["image"], generator=gen))
+        labels.copy_(torch.randint(0, cfg["classes"], (B,), generator=gen))
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        trainer.step(slot=i % SLOTS)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        trainer.step(slot=i % SLOTS)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_after = float(trainer.loss)
+    n_mean, n_max = trainer.active_stats()
+
+    # ---- instrumented pass: per-entry-point durations from HIP events on the launch stream
+    names = ["nnue_conv3x3_forward", "nnue_binarize_features", "nnue_ft_forward", "nnue_classifier_forward",
+             "nnue_cross_entropy", "nnue_classifier_backward", "nnue_ft_backward_weight", "nnue_ft_backward_values",
+             "nnue_ste_conv_backward", "nnue_sgd_step"]
+    timers = {k: [] for k in names}
+    isteps = max(5, min(50, args.steps))
+    for i in range(3):
+        trainer.step(slot=i % SLOTS, timers={k: [] for k in names})  # settle into eager mode
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    for i in range(isteps):
+        trainer.step(slot=i % SLOTS, timers=timers)
+    torch.cuda.synchronize(dev)
+    eager_ms = (time.perf_counter() - t1) * 1e3 / isteps
+    dur_us = {}
+    for k, pairs in timers.items():
+        v = sorted(a.elapsed_time(b) * 1e3 for a, b in pairs)
+        dur_us[k] = sum(v) / len(v) if v else 0.0
+
+    row = cfg["l1"] * 4  # bytes of one gathered / accumulated table row
+    alg = {  # algorithmic bytes per launch: fwd (n+1), value grad (n+1), weight grad n rows per image
+        "nnue_ft_forward": (n_mean + 1) * row * B,
+        "nnue_ft_backward_values": (n_mean + 1) * row * B,
+        "nnue_ft_backward_weight": n_mean * row * B,
+    }
+    kernels = {k: {"avg_us": round(dur_us[k], 2), **({"alg_GBps": round(alg[k] / dur_us[k] * 1e-3, 1)} if k in alg and dur_us[k] > 0 else {})}
+               for k in names}
+    dom = max(alg, key=lambda k: dur_us[k])
+    achieved = alg[dom] / (dur_us[dom] * 1e-6) / 1e9 if dur_us[dom] > 0 else 0.0
+    table_mb = model.input.weight.numel() * 4 / 1e6
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "alg_bytes_per_launch": int(alg[dom]), "avg_launch_us": round(dur_us[dom], 2),
+                "regime": ("table %.1f MB is L2/Infinity-Cache resident: algorithmic rate is cache bandwidth and may exceed the HBM peak"
+                           % table_mb) if table_mb < 200 else "table %.0f MB exceeds the Infinity Cache: HBM-bound" % table_mb}
+
+    if rank == 0:
+        out = {
+            "metric": "NNUE training images/sec (full step: fwd+bwd+clip+SGD)",
+            "value": round(B * world * args.steps / elapsed, 1),
+            "unit": "images/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: NNUE {cfg['image']}x{cfg['image']} grid {cfg['grid']}x{cfg['grid']}x{cfg['fps']} "
+                                   f"F={cfg['grid'] ** 2 * cfg['fps']} -> {cfg['l1']}/{cfg['l2']}/{cfg['l3']} -> {cfg['classes']}, "
+                                   f"batch {B}/GPU, SGD m0.9 wd2e-4 clip1.0",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "launch": "eager" if args.no_graph else "hipGraph",
+                       "mean_active_features": round(n_mean, 1), "max_active_features": n_max,
+                       "eager_ms_per_step_instrumented": round(eager_ms, 4), "loss_after": round(loss_after, 4)},
+            "roofline": roofline,
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

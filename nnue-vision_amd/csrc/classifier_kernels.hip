@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256) void l1_forward_mfma(const float* __restrict__
     col_ok[t] = col < L2;
     wrow[t] = w1 + (size_t)(col_ok[t] ? col : 0) * L1;
   }
-  for (int kb = k_lo; kb < k_lo + klen; kb += 16) {
+  // software pipeline: the operands of K block i+1 are requested before the MFMAs of block i issue
+  auto load_a = [&](int kb) {
     const int k = kb + 4 * q;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row_ok) {
@@ -145,10 +146,21 @@ __global__ __launch_bounds__(256) void l1_forward_mfma(const float* __restrict__
         a.x *= a2.x; a.y *= a2.y; a.z *= a2.z; a.w *= a2.w;
       }
     }
-    float4 bv[kFwdTileN];
+    return a;
+  };
+  auto load_b = [&](int kb, int t) {
+    return col_ok[t] ? *reinterpret_cast<const float4*>(wrow[t] + kb + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  const int k_hi = k_lo + klen;
+  float4 a = load_a(k_lo), bv[kFwdTileN];
 #pragma unroll
-    for (int t = 0; t < kFwdTileN; ++t)
-      bv[t] = col_ok[t] ? *reinterpret_cast<const float4*>(wrow[t] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = 0; t < kFwdTileN; ++t) bv[t] = load_b(k_lo, t);
+  for (int kb = k_lo; kb < k_hi; kb += 16) {
+    const int kn = kb + 16 < k_hi ? kb + 16 : kb;  // last iteration re-reads its own block (harmless)
+    const float4 an = load_a(kn);
+    float4 bn[kFwdTileN];
+#pragma unroll
+    for (int t = 0; t < kFwdTileN; ++t) bn[t] = load_b(kn, t);
 #pragma unroll
     for (int t = 0; t < kFwdTileN; ++t) {
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bv[t].x, acc[t], 0, 0, 0);
@@ -156,6 +168,9 @@ __global__ __launch_bounds__(256) void l1_forward_mfma(const float* __restrict__
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bv[t].z, acc[t], 0, 0, 0);
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bv[t].w, acc[t], 0, 0, 0);
     }
+    a = an;
+#pragma unroll
+    for (int t = 0; t < kFwdTileN; ++t) bv[t] = bn[t];
   }
   float* __restrict__ out = part + (size_t)ks * B * L2;
 #pragma unroll
@@ -206,12 +221,11 @@ __global__ __launch_bounds__(256) void l1_backward_w_mfma(const float* __restric
     else if (j < half) { cj[t] = j; cj2[t] = j + half; }
     else { cj[t] = j - half; cj2[t] = -1; }
   }
-  for (int b0 = b_lo; b0 < b_hi; b0 += 4) {
+  auto load_step = [&](int b0, float (&a)[kBwTileM], float (&bv)[kBwTileN]) {
     const int b = b0 + q;
     const bool ok = b < b_hi;
     const float* __restrict__ dz = d_z1 + (size_t)(ok ? b : 0) * L2 + mg * 16 * kBwTileM + r;
     const float* __restrict__ xr = x + (size_t)(ok ? b : 0) * L1;
-    float a[kBwTileM], bv[kBwTileN];
 #pragma unroll
     for (int i = 0; i < kBwTileM; ++i) a[i] = ok ? dz[16 * i] : 0.f;
 #pragma unroll
@@ -220,10 +234,19 @@ __global__ __launch_bounds__(256) void l1_backward_w_mfma(const float* __restric
       if (cj2[t] >= 0 && ok) v *= xr[cj2[t]];
       bv[t] = v;
     }
+  };
+  constexpr int kSteps = 4;  // K steps (of 4 samples) whose loads are issued together
+  for (int b0 = b_lo; b0 < b_hi; b0 += 4 * kSteps) {
+    float a[kSteps][kBwTileM], bv[kSteps][kBwTileN];
 #pragma unroll
-    for (int i = 0; i < kBwTileM; ++i)
+    for (int u = 0; u < kSteps; ++u) load_step(b0 + 4 * u, a[u], bv[u]);  // rows >= b_hi load as zero
 #pragma unroll
-      for (int t = 0; t < kBwTileN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv[t], acc[i][t], 0, 0, 0);
+    for (int u = 0; u < kSteps; ++u)
+#pragma unroll
+      for (int i = 0; i < kBwTileM; ++i)
+#pragma unroll
+        for (int t = 0; t < kBwTileN; ++t)
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], bv[u][t], acc[i][t], 0, 0, 0);
   }
   float* __restrict__ out = part + (size_t)ks * L2 * L1;
 #pragma unroll
@@ -274,16 +297,23 @@ __global__ __launch_bounds__(256) void l1_backward_x_mfma(const float* __restric
   const bool row_ok = row < B;
   const float* __restrict__ dz = d_z1 + (size_t)(row_ok ? row : 0) * L2;
   f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-  for (int kb = 0; kb < L2; kb += 16) {  // L2 % 16 == 0
+  auto load_ops = [&](int kb, float4& a, float (&b0v)[4], float (&b1v)[4]) {
     const int k = kb + 4 * q;
-    const float4 a = row_ok ? *reinterpret_cast<const float4*>(dz + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    a = row_ok ? *reinterpret_cast<const float4*>(dz + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float* __restrict__ wk = w1 + (size_t)k * L1 + r;
-    float b0v[4], b1v[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       b0v[e] = wk[(size_t)e * L1 + c0];
       b1v[e] = wk[(size_t)e * L1 + c1];
     }
+  };
+  float4 a;
+  float b0v[4], b1v[4];
+  load_ops(0, a, b0v, b1v);
+  for (int kb = 0; kb < L2; kb += 16) {  // L2 % 16 == 0
+    float4 an;
+    float n0[4], n1[4];
+    load_ops(kb + 16 < L2 ? kb + 16 : kb, an, n0, n1);  // prefetch the next K block
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0v[0], acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1v[0], acc1, 0, 0, 0);
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0v[1], acc0, 0, 0, 0);
@@ -292,6 +322,12 @@ __global__ __launch_bounds__(256) void l1_backward_x_mfma(const float* __restric
     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1v[2], acc1, 0, 0, 0);
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0v[3], acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1v[3], acc1, 0, 0, 0);
+    a = an;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      b0v[e] = n0[e];
+      b1v[e] = n1[e];
+    }
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -401,8 +437,10 @@ __global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restric
   }
   float acc = 0.f;
   if (pb) {
+#pragma unroll 8
     for (int b = lane; b < B; b += 64) acc = fmaf(pa[(size_t)b * sa], pb[(size_t)b * sb], acc);
   } else {
+#pragma unroll 8
     for (int b = lane; b < B; b += 64) acc += pa[(size_t)b * sa];
   }
   acc = wave_sum(acc);

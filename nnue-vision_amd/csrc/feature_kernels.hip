@@ -182,12 +182,18 @@ __global__ __launch_bounds__(256) void ste_conv_backward_stage1(const float* __r
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-__global__ __launch_bounds__(64) void ste_conv_backward_stage2(const float* __restrict__ partial, int chunks, int fps,
-                                                               float* __restrict__ d_thr, float* __restrict__ d_weight) {
-  const int c = blockIdx.x, q = threadIdx.x;
-  if (q >= 28) return;
+// one wave per (channel, term): lanes stride over the chunk partials, fixed-shape tree sum
+__global__ __launch_bounds__(256) void ste_conv_backward_stage2(const float* __restrict__ partial, int chunks, int fps,
+                                                                float* __restrict__ d_thr, float* __restrict__ d_weight) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (o >= fps * 28) return;
+  const int c = o / 28, q = o - c * 28;
   float acc = 0.0f;
-  for (int k = 0; k < chunks; ++k) acc += partial[((size_t)k * fps + c) * 28 + q];
+  for (int k = lane; k < chunks; k += 64) acc += partial[((size_t)k * fps + c) * 28 + q];
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) acc += __shfl_xor(acc, sft);
+  if (lane != 0) return;
   if (q == 27) {
     if (d_thr) d_thr[c] = -acc;
   } else if (d_weight) {
@@ -195,8 +201,9 @@ __global__ __launch_bounds__(64) void ste_conv_backward_stage2(const float* __re
   }
 }
 
+// about two workgroups per CU: enough to fill the chip, few enough that stage 2 stays trivial
 int ste_chunks(int B, int fps) {
-  int chunks = 2048 / (fps > 0 ? fps : 1);
+  int chunks = 512 / (fps > 0 ? fps : 1);
   if (chunks < 1) chunks = 1;
   if (chunks > B) chunks = B;
   return chunks;
@@ -263,6 +270,6 @@ extern "C" int nnue_ste_conv_backward(const float* images, const float* conv_out
   float* partial = static_cast<float*>(scratch);
   hipLaunchKernelGGL(ste_conv_backward_stage1, dim3(fps, chunks), dim3(256), 0, s, images, conv_out, thr, d_conv_out, B, H,
                      W, fps, stride, Gh, Gw, spc, partial);
-  hipLaunchKernelGGL(ste_conv_backward_stage2, dim3(fps), dim3(64), 0, s, partial, chunks, fps, d_thr, d_weight);
+  hipLaunchKernelGGL(ste_conv_backward_stage2, dim3((fps * 28 + 3) / 4), dim3(256), 0, s, partial, chunks, fps, d_thr, d_weight);
   return nnue_launch_status("nnue_ste_conv_backward");
 }

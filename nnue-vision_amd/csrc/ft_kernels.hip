@@ -145,8 +145,8 @@ __global__ __launch_bounds__(256) void ft_backward_weight_wide(const float* __re
   const int col = (blockIdx.y * 4 + wave) * 256 + lane * 4;
   if (col >= L1) return;
   const bool is_bias = (f == F);
+  if ((is_bias ? d_bias : d_weight) == nullptr) return;  // output not requested; uniform per block
   float* __restrict__ dst = is_bias ? d_bias : d_weight + (size_t)f * L1;
-  if (dst == nullptr) return;  // uniform per block
   const float* __restrict__ crow = coefT + (size_t)(is_bias ? 0 : f) * ldb;
   const float* __restrict__ g = d_out + col;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -187,8 +187,8 @@ __global__ __launch_bounds__(256) void ft_backward_weight_simple(const float* __
   const int col = blockIdx.y * 256 + threadIdx.x;
   if (col >= L1) return;
   const bool is_bias = (f == F);
+  if ((is_bias ? d_bias : d_weight) == nullptr) return;
   float* __restrict__ dst = is_bias ? d_bias : d_weight + (size_t)f * L1;
-  if (dst == nullptr) return;
   const float* __restrict__ crow = coefT + (size_t)(is_bias ? 0 : f) * ldb;
   float acc = 0.f;
   for (int b = 0; b < B; ++b) {
@@ -222,6 +222,11 @@ __global__ __launch_bounds__(256) void ft_backward_values_wide(const float* __re
   for (int s = 0; s < S; ++s)
     g[s] = *reinterpret_cast<const float4*>(d_out + (size_t)b * L1 + s * 256 + lane * 4);
   const float* __restrict__ Wl = W + lane * 4;
+
+  // zero this sample's destination row, then scatter the dot products over it (ordered by the barrier:
+  // both writes come from this workgroup)
+  for (int i = threadIdx.x; i < dst_ld; i += 256) dst[(size_t)b * dst_ld + i] = 0.0f;
+  __syncthreads();
 
   for (int k0 = wave * 16; k0 < cnt; k0 += 64) {
     float p[16];
@@ -378,10 +383,11 @@ extern "C" int nnue_ft_backward_values(const float* d_out, const float* weight, 
   NNUE_REQUIRE(B > 0 && F > 0 && L1 > 0 && cap > 0 && dst_ld > 0, NNUE_E_ARG,
                "nnue_ft_backward_values: B=%d F=%d L1=%d cap=%d dst_ld=%d must be positive", B, F, L1, cap, dst_ld);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(dst, 0, (size_t)B * dst_ld * sizeof(float), s) != hipSuccess)
-    return nnue_launch_status("nnue_ft_backward_values(memset)");
   const int S = wide_ok(L1) ? L1 / 256 : 0;
-  if (S == 1 || S == 2 || S == 4 || S == 8) {
+  const bool wide = (S == 1 || S == 2 || S == 4 || S == 8);
+  if (!wide && hipMemsetAsync(dst, 0, (size_t)B * dst_ld * sizeof(float), s) != hipSuccess)
+    return nnue_launch_status("nnue_ft_backward_values(memset)");
+  if (wide) {  // the wide kernel zero-fills its own rows
     NNUE_REQUIRE(nnue_aligned16(d_out) && nnue_aligned16(weight), NNUE_E_ARG,
                  "nnue_ft_backward_values: pointers must be 16-byte aligned");
     const dim3 grid(B), block(256);

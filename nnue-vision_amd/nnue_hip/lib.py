@@ -76,11 +76,50 @@ def load() -> ctypes.CDLL:
     return lib
 
 
+_recording: Optional[list] = None  # when a list: every C call is also appended as (name, fn, args-without-stream)
+
+
+class record_calls:
+    """Context manager: collects the raw C calls made by the wrappers so that a fixed kernel sequence
+    can later be replayed with no Python between launches (``run_plan``) -- eagerly or under hipGraph
+    capture.  The last argument of every launching entry point is the stream; it is re-read at replay."""
+
+    def __enter__(self):
+        global _recording
+        self.prev, _recording = _recording, []
+        self.calls = _recording
+        return self.calls
+
+    def __exit__(self, *exc):
+        global _recording
+        _recording = self.prev
+        return False
+
+
 def _call(name: str, *args) -> None:
     lib = load()
-    rc = getattr(lib, name)(*args)
+    fn = getattr(lib, name)
+    rc = fn(*args)
     if rc != 0:
         raise NnueHipError(f"{name} failed (code {rc}): {lib.nnue_hip_last_error().decode()}")
+    if _recording is not None:
+        _recording.append((name, fn, args[:-1]))
+
+
+def run_plan(plan, stream_ptr: int, timers=None) -> None:
+    """Replays recorded calls on `stream_ptr`.  timers: {entry-point name: list} -- a (start, end) pair of
+    torch events is recorded around each matching call on the current stream and appended to the list."""
+    for name, fn, args in plan:
+        if timers is not None and name in timers:
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
+            rc = fn(*args, stream_ptr)
+            t1.record()
+            timers[name].append((t0, t1))
+        else:
+            rc = fn(*args, stream_ptr)
+        if rc != 0:
+            raise NnueHipError(f"{name} failed (code {rc}): {load().nnue_hip_last_error().decode()}")
 
 
 def _stream(t: torch.Tensor) -> int:

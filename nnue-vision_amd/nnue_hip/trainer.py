@@ -1,0 +1,288 @@
+"""Training step of the NNUE hot path on MI355X, one process per GPU.
+
+What train.py:359-366 does per batch (zero_grad, forward, cross-entropy, backward, clip_grad_norm_,
+SGD step) is one fixed sequence of HIP kernels here, working on preallocated buffers:
+
+    conv -> binarise+compact -> FT gather-accumulate -> pairwise+classifier -> cross-entropy
+         -> classifier backward -> FT weight gather-sum -> FT value gather-dot -> STE/conv backward
+         -> [all-reduce of ONE flat gradient buffer over RCCL when world > 1] -> fused clip + SGD
+
+* every trainable parameter (all but nnue2score, which never has a gradient) lives in one flat fp32
+  buffer; the module's parameters are views into it, so state_dict()/serialize keep working.  Gradients
+  and momentum have matching flat buffers -- the all-reduce is a single call on a single buffer
+  (3.8 MB at the CIFAR configs: latency-bound on xGMI, so one message, not one per tensor);
+* shapes are static, nothing synchronises with the host, so the local part of the step is captured into
+  a hipGraph and replayed (the C ABI launches on torch's current stream);
+* data parallel = each rank takes an equal slice of the global batch; mean-loss gradients are summed
+  by the all-reduce and scaled by 1/world inside the SGD kernel, where the *global* gradient norm is
+  clipped -- every rank therefore applies the identical update.
+
+``FlatLayout`` and ``DataParallel`` are device-agnostic plumbing (covered by gloo tests on CPU);
+``NnueTrainer`` is GPU-only.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import lib
+
+SKIP = ("nnue2score",)  # no gradient ever reaches it (reference tests/test_model.py:179-182)
+
+
+@dataclass
+class FlatLayout:
+    names: List[str]
+    shapes: List[Tuple[int, ...]]
+    offsets: List[int]
+    count: int  # padded element count of the flat buffers
+
+    @staticmethod
+    def of(model: torch.nn.Module, align: int = 4) -> "FlatLayout":
+        names, shapes, offsets, off = [], [], [], 0
+        for k, p in model.named_parameters():
+            if k in SKIP:
+                continue
+            names.append(k)
+            shapes.append(tuple(p.shape))
+            offsets.append(off)
+            off += (p.numel() + align - 1) // align * align  # 16-byte aligned starts for the float4 kernels
+        return FlatLayout(names, shapes, offsets, off)
+
+    def views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        out = {}
+        for k, s, o in zip(self.names, self.shapes, self.offsets):
+            n = 1
+            for d in s:
+                n *= d
+            out[k] = flat[o:o + n].view(s)
+        return out
+
+    def pack(self, tensors: Dict[str, torch.Tensor], device=None) -> torch.Tensor:
+        some = next(iter(tensors.values()))
+        flat = torch.zeros(self.count, dtype=torch.float32, device=device if device is not None else some.device)
+        for k, v in self.views(flat).items():
+            v.copy_(tensors[k])
+        return flat
+
+
+class DataParallel:
+    """Batch sharding + the one collective of the step.  Backend: "nccl" (= RCCL over xGMI) on GPUs,
+    "gloo" in the CPU tests."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.enabled = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.enabled else 1
+        self.rank = dist.get_rank(group) if self.enabled else 0
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+    def shard(self, global_batch: int) -> slice:
+        if global_batch % self.world:
+            raise ValueError(f"global batch {global_batch} is not divisible by world size {self.world}")
+        per = global_batch // self.world
+        return slice(self.rank * per, (self.rank + 1) * per)
+
+    def broadcast(self, flat: torch.Tensor) -> None:
+        if self.world > 1:
+            dist.broadcast(flat, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+
+    def allreduce_sum(self, flat: torch.Tensor, async_op: bool = False):
+        if self.world > 1:
+            return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        return None
+
+
+class NnueTrainer:
+    """Owns the flat buffers and the activation workspace for one (batch, H, W) shape."""
+
+    def __init__(self, model, batch_size: int, image_hw: Tuple[int, int], lr: float, momentum: float = 0.0,
+                 weight_decay: float = 0.0, max_grad_norm: float = 0.0, group=None, use_graph: bool = True,
+                 input_slots: int = 1):
+        lib.load()
+        p0 = next(model.parameters())
+        if not p0.is_cuda:
+            raise lib.NnueHipError("NnueTrainer needs the model on the GPU (no CPU fallback)")
+        self.model, self.dev = model, p0.device
+        self.lr, self.momentum, self.weight_decay, self.max_grad_norm = lr, momentum, weight_decay, max_grad_norm
+        self.dp = DataParallel(group)
+        self.B, (self.H, self.W) = batch_size, image_hw
+        self.stride = int(model.conv.stride[0])
+        self.fps = model.conv.out_channels
+        self.F, self.L1 = model.input.weight.shape
+        lin = model.classifier._linears()
+        self.L2, self.L3, self.C = lin[0].out_features, lin[1].out_features, lin[2].out_features
+        self.clip = float(model.classifier.clip_activations or 0.0)
+        self.gh, self.gw = lib.conv_out_hw(self.H, self.W, self.stride)
+        self.P = self.fps * self.gh * self.gw
+
+        # ---- flat parameter / gradient / momentum buffers; module parameters become views
+        self.layout = FlatLayout.of(model)
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        state = {k: p.detach() for k, p in model.named_parameters() if k not in SKIP}
+        self.flat_params = self.layout.pack(state)
+        self.flat_grads = torch.zeros(self.layout.count, **f32)
+        self.flat_momentum = torch.zeros(self.layout.count, **f32) if momentum else None
+        self.dp.broadcast(self.flat_params)  # identical replicas even if ranks were seeded differently
+        self.p = self.layout.views(self.flat_params)
+        self.g = self.layout.views(self.flat_grads)
+        for k, prm in model.named_parameters():
+            if k not in SKIP:
+                prm.data = self.p[k]
+                prm.grad = self.g[k]
+
+        # ---- static activations and scratch
+        B = self.B
+        # input ring: a loader fills slot k while slot k-1 trains; kernels read the slots in place
+        self.inputs = [(torch.empty((B, 3, self.H, self.W), **f32), torch.empty((B,), dtype=torch.int64, device=self.dev))
+                       for _ in range(max(1, input_slots))]
+        self.images, self.labels = self.inputs[0]
+        self.conv_out = torch.empty((B, self.fps, self.gh, self.gw), **f32)
+        self.act = lib.ActList.empty(B, self.P, self.F, self.dev)
+        self.ft = torch.empty((B, self.L1), **f32)
+        self.h1 = torch.empty((B, self.L2), **f32)
+        self.h2 = torch.empty((B, self.L3), **f32)
+        self.logits = torch.empty((B, self.C), **f32)
+        self.sample_loss = torch.empty((B,), **f32)
+        self.loss = torch.zeros((), **f32)
+        self.d_logits = torch.empty((B, self.C), **f32)
+        self.d_ft = torch.empty((B, self.L1), **f32)
+        self.d_conv_out = torch.empty((B, self.P), **f32)
+        self.grad_norm = torch.zeros((), **f32)
+        u8 = dict(dtype=torch.uint8, device=self.dev)
+        self.cls_scratch = torch.empty((lib.classifier_scratch_bytes(B, self.L1, self.L2, self.L3),), **u8)
+        self.ste_scratch = torch.empty((max(16, lib.load().nnue_ste_conv_backward_scratch(B, self.fps, self.gh, self.gw)),), **u8)
+        self.sgd_scratch = torch.empty((lib.sgd_scratch_bytes(self.layout.count),), **u8)
+        self.steps_done = 0
+        self.use_graph = use_graph
+        self._g_local, self._g_update = {}, None
+        self._plan_local = self._plan_update_first = self._plan_update = None
+        self._side = torch.cuda.Stream(device=self.dev) if use_graph else None
+
+    # ------------------------------------------------------------------ kernel sequences
+    def _cls_params(self):
+        p = self.p
+        return [p[f"classifier.classifier.{i}.{n}"] for i in (0, 2, 4) for n in ("weight", "bias")]
+
+    def _forward(self) -> None:
+        p = self.p
+        lib.conv3x3_forward(self.images, p["conv.weight"], self.stride, out=self.conv_out)
+        lib.binarize_features(self.conv_out, p["visual_threshold"], self.F, act=self.act)
+        lib.ft_forward(p["input.weight"], p["input.bias"], self.act, out=self.ft)
+        lib.classifier_forward(self.ft, True, *self._cls_params(), self.clip, scratch=self.cls_scratch,
+                               out=(self.h1, self.h2, self.logits))
+
+    def _local_step(self) -> None:
+        """forward + loss + backward into the flat gradient buffer (every element is overwritten)."""
+        p, g = self.p, self.g
+        self._forward()
+        lib.cross_entropy(self.logits, self.labels, 1.0, out=(self.sample_loss, self.loss, self.d_logits))
+        w1, _, w2, _, w3, _ = self._cls_params()
+        cls_grads = tuple(g[f"classifier.classifier.{i}.{n}"] for i in (0, 2, 4) for n in ("weight", "bias"))
+        lib.classifier_backward(self.ft, True, w1, w2, w3, self.h1, self.h2, self.d_logits, self.clip,
+                                scratch=self.cls_scratch, grads=cls_grads, d_x=self.d_ft)
+        lib.ft_backward_weight(self.d_ft, self.act, self.F, d_weight=g["input.weight"], d_bias=g["input.bias"])
+        lib.ft_backward_values(self.d_ft, p["input.weight"], self.act, self.P, dst=self.d_conv_out)
+        lib.ste_conv_backward(self.images, self.conv_out, p["visual_threshold"], self.d_conv_out, self.stride,
+                              d_thr=g["visual_threshold"], d_weight=g["conv.weight"], scratch=self.ste_scratch)
+
+    def _update(self, first: bool) -> None:
+        lib.sgd_step(self.flat_params, self.flat_grads, self.flat_momentum, self.lr, self.momentum, self.weight_decay,
+                     self.max_grad_norm, self.dp.grad_scale, first, self.grad_norm, self.sgd_scratch)
+
+    def _capture(self, plan) -> torch.cuda.CUDAGraph:
+        graph = torch.cuda.CUDAGraph()
+        self._side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self._side):
+            with torch.cuda.graph(graph, stream=self._side):
+                lib.run_plan(plan, torch.cuda.current_stream(self.dev).cuda_stream)
+        torch.cuda.current_stream(self.dev).wait_stream(self._side)
+        return graph
+
+    def _plans(self):
+        """Records the three fixed call sequences once (this also executes them once; the update plans are
+        recorded on throw-away copies of the buffers' contents, which are restored afterwards)."""
+        if self._plan_local is None:
+            with lib.record_calls() as calls:
+                self._local_step()
+            self._plan_local = list(calls)
+            keep = (self.flat_params.clone(), self.flat_grads.clone(),
+                    None if self.flat_momentum is None else self.flat_momentum.clone(), self.grad_norm.clone())
+            with lib.record_calls() as calls:
+                self._update(True)
+            self._plan_update_first = list(calls)
+            with lib.record_calls() as calls:
+                self._update(False)
+            self._plan_update = list(calls)
+            self.flat_params.copy_(keep[0])
+            self.flat_grads.copy_(keep[1])
+            if keep[2] is not None:
+                self.flat_momentum.copy_(keep[2])
+            self.grad_norm.copy_(keep[3])
+        return self._plan_local, self._plan_update_first, self._plan_update
+
+    def _local_plan_for(self, slot: int):
+        """The recorded sequence with slot 0's input pointers swapped for `slot`'s."""
+        local = self._plan_local
+        if slot == 0:
+            return local
+        swap = {self.inputs[0][0].data_ptr(): self.inputs[slot][0].data_ptr(),
+                self.inputs[0][1].data_ptr(): self.inputs[slot][1].data_ptr()}
+        return [(name, fn, tuple(swap.get(a, a) if isinstance(a, int) else a for a in args)) for name, fn, args in local]
+
+    # ------------------------------------------------------------------ public
+    def step(self, images: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None, slot: int = 0,
+             timers=None) -> torch.Tensor:
+        """One optimizer step on this rank's slice.  Returns the local mean loss (device scalar, no sync).
+
+        ``images``/``labels`` are copied into input slot ``slot`` first; pass None to train on what the slot
+        already holds (zero-copy: fill ``trainer.inputs[slot]`` directly).  With ``timers`` ({C entry point:
+        list}) the step runs eagerly from the recorded plan and brackets the named calls with HIP events on the
+        launch stream (bench.py's per-kernel durations)."""
+        buf_images, buf_labels = self.inputs[slot]
+        if images is not None:
+            if tuple(images.shape) != tuple(buf_images.shape) or labels is None or tuple(labels.shape) != (self.B,):
+                raise ValueError(f"trainer was built for images {tuple(buf_images.shape)} / labels ({self.B},)")
+            buf_images.copy_(images, non_blocking=True)
+            buf_labels.copy_(labels, non_blocking=True)
+        if self._plan_local is None and slot != 0:
+            self.inputs[0][0].copy_(buf_images)
+            self.inputs[0][1].copy_(buf_labels)
+        _, upd_first, upd = self._plans()
+        first = self.steps_done == 0
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        if self.use_graph and timers is None:
+            if slot not in self._g_local:
+                self._g_local[slot] = self._capture(self._local_plan_for(slot))
+            if self._g_update is None:
+                self._g_update = self._capture(upd)
+            self._g_local[slot].replay()
+        else:
+            lib.run_plan(self._local_plan_for(slot), stream, timers)
+        self.dp.allreduce_sum(self.flat_grads)
+        if first:
+            lib.run_plan(upd_first, stream, timers)
+        elif self.use_graph and timers is None:
+            self._g_update.replay()
+        else:
+            lib.run_plan(upd, stream, timers)
+        self.steps_done += 1
+        return self.loss
+
+    @torch.no_grad()
+    def evaluate(self, images: torch.Tensor) -> torch.Tensor:
+        """Forward only on a full-size batch; returns logits (a view of the static buffer)."""
+        self.inputs[0][0].copy_(images, non_blocking=True)
+        self._forward()
+        return self.logits
+
+    def active_stats(self) -> Tuple[float, int]:
+        """(mean, max) active features per image of the last batch -- reads back; not for timed regions."""
+        n = self.act.n.float()
+        return float(n.mean()), int(n.max())
