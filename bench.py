@@ -144,9 +144,10 @@ def main():
     n_mean, n_max = trainer.active_stats()
 
     # ---- instrumented pass: per-entry-point durations from HIP events on the launch stream
-    names = ["nnue_conv3x3_forward", "nnue_binarize_features", "nnue_ft_forward", "nnue_classifier_forward",
-             "nnue_cross_entropy", "nnue_classifier_backward", "nnue_ft_backward_weight", "nnue_ft_backward_values",
-             "nnue_ste_conv_backward", "nnue_sgd_step"]
+    ftp = "nnue_ftb" if trainer.use_bits else "nnue_ft"  # bit-mask/LDS-staged kernels or id-list kernels
+    names = ["nnue_conv3x3_forward", "nnue_binarize_bits" if trainer.use_bits else "nnue_binarize_features",
+             f"{ftp}_forward", "nnue_classifier_forward", "nnue_cross_entropy", "nnue_classifier_backward",
+             f"{ftp}_backward_weight", f"{ftp}_backward_values", "nnue_ste_conv_backward", "nnue_sgd_step"]
     timers = {k: [] for k in names}
     isteps = max(5, min(50, args.steps))
     for i in range(3):
@@ -164,9 +165,9 @@ def main():
 
     row = cfg["l1"] * 4  # bytes of one gathered / accumulated table row
     alg = {  # algorithmic bytes per launch: fwd (n+1), value grad (n+1), weight grad n rows per image
-        "nnue_ft_forward": (n_mean + 1) * row * B,
-        "nnue_ft_backward_values": (n_mean + 1) * row * B,
-        "nnue_ft_backward_weight": n_mean * row * B,
+        f"{ftp}_forward": (n_mean + 1) * row * B,
+        f"{ftp}_backward_values": (n_mean + 1) * row * B,
+        f"{ftp}_backward_weight": n_mean * row * B,
     }
     kernels = {k: {"avg_us": round(dur_us[k], 2), **({"alg_GBps": round(alg[k] / dur_us[k] * 1e-3, 1)} if k in alg and dur_us[k] > 0 else {})}
                for k in names}

@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -36,6 +36,12 @@ SIGNATURES = {
     "nnue_ft_backward_weight": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
     "nnue_ft_backward_values": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int,
                                          _c_p, _c_int, _c_p]),
+    "nnue_ftb_supported": (_c_int, [_c_int]),
+    "nnue_binarize_bits": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_int, _c_p, _c_int,
+                                    _c_p, _c_p, _c_p]),
+    "nnue_ftb_forward": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p]),
+    "nnue_ftb_backward_weight": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
+    "nnue_ftb_backward_values": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p]),
     "nnue_classifier_scratch": (_c_i64, [_c_int, _c_int, _c_int, _c_int]),
     "nnue_classifier_forward": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_f,
                                          _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p,
@@ -304,6 +310,113 @@ def ft_backward_values(d_out: torch.Tensor, weight: torch.Tensor, act: ActList, 
         raise ValueError("ft_backward_values: dst has the wrong size")
     _call("nnue_ft_backward_values", d_out.data_ptr(), weight.data_ptr(), act.rows.data_ptr(), act.pos.data_ptr(),
           act.n.data_ptr(), act.cap, b, f, l1, dst.data_ptr(), dst_ld, _stream(d_out))
+    return dst
+
+
+# ---------------------------------------------------------------------------- FeatureTransformer, binary features
+@dataclass
+class FeatureBits:
+    """Bit-mask form of the active features of one batch (layout: include/nnue_hip.h)."""
+    maskW: torch.Tensor  # int64 [B, pw64]     position bits per sample
+    maskT: torch.Tensor  # int64 [F+1, bw64]   sample bits per table row (+ bias row)
+    sink: torch.Tensor   # float32 [B]         active ids >= F-1
+    n: torch.Tensor      # int32 [B]           active positions
+    positions: int       # P = fps*Gh*Gw
+    num_rows: int        # F
+
+    @property
+    def batch(self) -> int:
+        return self.n.shape[0]
+
+    @staticmethod
+    def empty(batch: int, positions: int, num_rows: int, device) -> "FeatureBits":
+        pw64, bw64 = round_up(round_up(positions, 64) // 64, 2), round_up(round_up(batch, 64) // 64, 2)
+        return FeatureBits(torch.empty((batch, pw64), dtype=torch.int64, device=device),
+                           torch.empty((num_rows + 1, bw64), dtype=torch.int64, device=device),
+                           torch.empty((batch,), dtype=torch.float32, device=device),
+                           torch.empty((batch,), dtype=torch.int32, device=device), positions, num_rows)
+
+
+def ftb_supported(l1: int) -> bool:
+    return bool(load().nnue_ftb_supported(int(l1)))
+
+
+def use_bit_path(num_rows: int, l1: int) -> bool:
+    """Which FeatureTransformer kernels the fused path uses for binary features.
+
+    "list" = id-list gather kernels (every sample gathers its rows from L2: fastest while the table is
+    L2-resident); "bits" = bit-mask kernels that stage table tiles in LDS once per sample tile (cut
+    memory-side traffic by the tile factor: for tables beyond the caches).  NNUE_FT_PATH=list|bits forces one;
+    default "auto" switches on the table size."""
+    mode = os.environ.get("NNUE_FT_PATH", "auto")
+    if mode == "list" or not ftb_supported(l1):
+        return False
+    if mode == "bits":
+        return True
+    return num_rows * l1 * 4 > BITS_PATH_MIN_TABLE_BYTES
+
+
+BITS_PATH_MIN_TABLE_BYTES = 32 << 20  # one XCD's L2 is 4 MiB; 32 MiB aggregate
+
+
+def binarize_bits(conv_out: torch.Tensor, thr: torch.Tensor, num_rows: int,
+                  bits: Optional[FeatureBits] = None) -> FeatureBits:
+    conv_out = _need(conv_out, torch.float32, "conv_out")
+    if conv_out.dim() != 4:
+        raise ValueError(f"conv_out: expected [B,fps,Gh,Gw], got {tuple(conv_out.shape)}")
+    b, fps, gh, gw = conv_out.shape
+    thr = _need(thr.reshape(-1), torch.float32, "threshold", (fps,))
+    if bits is None:
+        bits = FeatureBits.empty(b, fps * gh * gw, num_rows, conv_out.device)
+    elif bits.batch != b or bits.positions != fps * gh * gw or bits.num_rows != num_rows:
+        raise ValueError("binarize_bits: bit buffers do not match the map")
+    _call("nnue_binarize_bits", conv_out.data_ptr(), thr.data_ptr(), b, fps, gh, gw, num_rows, bits.maskW.data_ptr(),
+          bits.maskW.shape[1], bits.maskT.data_ptr(), bits.maskT.shape[1], bits.sink.data_ptr(), bits.n.data_ptr(),
+          _stream(conv_out))
+    return bits
+
+
+def ftb_forward(weight: torch.Tensor, bias: torch.Tensor, bits: FeatureBits, out: Optional[torch.Tensor] = None):
+    weight = _need(weight, torch.float32, "input.weight")
+    f, l1 = weight.shape
+    bias = _need(bias, torch.float32, "input.bias", (l1,))
+    if f != bits.num_rows:
+        raise ValueError("ftb_forward: bits were built for a different table")
+    if out is None:
+        out = torch.empty((bits.batch, l1), dtype=torch.float32, device=weight.device)
+    _call("nnue_ftb_forward", weight.data_ptr(), bias.data_ptr(), bits.maskW.data_ptr(), bits.maskW.shape[1],
+          bits.sink.data_ptr(), bits.batch, f, bits.positions, l1, out.data_ptr(), _stream(weight))
+    return out
+
+
+def ftb_backward_weight(d_out: torch.Tensor, bits: FeatureBits, d_weight: Optional[torch.Tensor] = None,
+                        d_bias: Optional[torch.Tensor] = None, want_weight: bool = True, want_bias: bool = True):
+    d_out = _need(d_out, torch.float32, "d_out")
+    b, l1 = d_out.shape
+    if b != bits.batch:
+        raise ValueError("ftb_backward_weight: bits do not match d_out")
+    if want_weight and d_weight is None:
+        d_weight = torch.empty((bits.num_rows, l1), dtype=torch.float32, device=d_out.device)
+    if want_bias and d_bias is None:
+        d_bias = torch.empty((l1,), dtype=torch.float32, device=d_out.device)
+    _call("nnue_ftb_backward_weight", d_out.data_ptr(), bits.maskT.data_ptr(), bits.maskT.shape[1], bits.sink.data_ptr(),
+          b, bits.num_rows, l1, _ptr(d_weight if want_weight else None), _ptr(d_bias if want_bias else None), _stream(d_out))
+    return d_weight, d_bias
+
+
+def ftb_backward_values(d_out: torch.Tensor, weight: torch.Tensor, bits: FeatureBits,
+                        dst: Optional[torch.Tensor] = None) -> torch.Tensor:
+    d_out = _need(d_out, torch.float32, "d_out")
+    weight = _need(weight, torch.float32, "input.weight")
+    b, l1 = d_out.shape
+    if weight.shape != (bits.num_rows, l1) or b != bits.batch:
+        raise ValueError("ftb_backward_values: shape mismatch")
+    if dst is None:
+        dst = torch.empty((b, bits.positions), dtype=torch.float32, device=d_out.device)
+    elif dst.numel() != b * bits.positions:
+        raise ValueError("ftb_backward_values: dst has the wrong size")
+    _call("nnue_ftb_backward_values", d_out.data_ptr(), weight.data_ptr(), bits.maskW.data_ptr(), bits.maskW.shape[1],
+          b, bits.num_rows, bits.positions, l1, dst.data_ptr(), _stream(d_out))
     return dst
 
 

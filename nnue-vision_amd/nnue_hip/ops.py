@@ -62,25 +62,37 @@ class NnueFn(torch.autograd.Function):
     def forward(ctx, images, thr, conv_w, ft_w, ft_b, w1, b1, w2, b2, w3, b3, stride, clip):
         images = images.contiguous()
         conv_out = lib.conv3x3_forward(images, conv_w, stride)
-        act = lib.binarize_features(conv_out, thr, ft_w.shape[0])
-        ft = lib.ft_forward(ft_w, ft_b, act)
+        # binary features: bit masks + LDS-staged tiles when the width allows, id lists otherwise
+        ctx.use_bits = lib.use_bit_path(ft_w.shape[0], ft_w.shape[1])
+        if ctx.use_bits:
+            feats = lib.binarize_bits(conv_out, thr, ft_w.shape[0])
+            ft = lib.ftb_forward(ft_w, ft_b, feats)
+        else:
+            feats = lib.binarize_features(conv_out, thr, ft_w.shape[0])
+            ft = lib.ft_forward(ft_w, ft_b, feats)
         h1, h2, logits = lib.classifier_forward(ft, True, w1, b1, w2, b2, w3, b3, clip)
-        ctx.act, ctx.stride, ctx.clip = act, stride, clip
+        ctx.feats, ctx.stride, ctx.clip = feats, stride, clip
         ctx.save_for_backward(images, thr, conv_w, conv_out, ft_w, ft, w1, w2, w3, h1, h2)
         return logits
 
     @staticmethod
     def backward(ctx, d_logits):
         images, thr, conv_w, conv_out, ft_w, ft, w1, w2, w3, h1, h2 = ctx.saved_tensors
-        act = ctx.act
+        feats = ctx.feats
         need = ctx.needs_input_grad
         d_ft, g_cls = lib.classifier_backward(ft, True, w1, w2, w3, h1, h2, d_logits.contiguous(), ctx.clip)
         d_ftw = d_ftb = d_thr = d_conv_w = d_images = None
         if need[3] or need[4]:
-            d_ftw, d_ftb = lib.ft_backward_weight(d_ft, act, ft_w.shape[0], want_weight=need[3], want_bias=need[4])
+            if ctx.use_bits:
+                d_ftw, d_ftb = lib.ftb_backward_weight(d_ft, feats, want_weight=need[3], want_bias=need[4])
+            else:
+                d_ftw, d_ftb = lib.ft_backward_weight(d_ft, feats, ft_w.shape[0], want_weight=need[3], want_bias=need[4])
         if need[0] or need[1] or need[2]:
             # value gradient of the binary features == d(conv_out) (identity STE, nnue.py:33)
-            d_conv_out = lib.ft_backward_values(d_ft, ft_w, act, act.cap).view_as(conv_out)
+            if ctx.use_bits:
+                d_conv_out = lib.ftb_backward_values(d_ft, ft_w, feats).view_as(conv_out)
+            else:
+                d_conv_out = lib.ft_backward_values(d_ft, ft_w, feats, feats.cap).view_as(conv_out)
             if need[1] or need[2]:
                 d_thr, d_conv_w = lib.ste_conv_backward(images, conv_out, thr, d_conv_out, ctx.stride)
                 d_thr = d_thr.view_as(thr)

@@ -144,7 +144,10 @@ class NnueTrainer:
                        for _ in range(max(1, input_slots))]
         self.images, self.labels = self.inputs[0]
         self.conv_out = torch.empty((B, self.fps, self.gh, self.gw), **f32)
-        self.act = lib.ActList.empty(B, self.P, self.F, self.dev)
+        # binary features: bit masks + LDS-staged FT kernels when the width allows, id lists otherwise
+        self.use_bits = lib.use_bit_path(self.F, self.L1)
+        self.bits = lib.FeatureBits.empty(B, self.P, self.F, self.dev) if self.use_bits else None
+        self.act = None if self.use_bits else lib.ActList.empty(B, self.P, self.F, self.dev)
         self.ft = torch.empty((B, self.L1), **f32)
         self.h1 = torch.empty((B, self.L2), **f32)
         self.h2 = torch.empty((B, self.L3), **f32)
@@ -173,8 +176,12 @@ class NnueTrainer:
     def _forward(self) -> None:
         p = self.p
         lib.conv3x3_forward(self.images, p["conv.weight"], self.stride, out=self.conv_out)
-        lib.binarize_features(self.conv_out, p["visual_threshold"], self.F, act=self.act)
-        lib.ft_forward(p["input.weight"], p["input.bias"], self.act, out=self.ft)
+        if self.use_bits:
+            lib.binarize_bits(self.conv_out, p["visual_threshold"], self.F, bits=self.bits)
+            lib.ftb_forward(p["input.weight"], p["input.bias"], self.bits, out=self.ft)
+        else:
+            lib.binarize_features(self.conv_out, p["visual_threshold"], self.F, act=self.act)
+            lib.ft_forward(p["input.weight"], p["input.bias"], self.act, out=self.ft)
         lib.classifier_forward(self.ft, True, *self._cls_params(), self.clip, scratch=self.cls_scratch,
                                out=(self.h1, self.h2, self.logits))
 
@@ -187,8 +194,12 @@ class NnueTrainer:
         cls_grads = tuple(g[f"classifier.classifier.{i}.{n}"] for i in (0, 2, 4) for n in ("weight", "bias"))
         lib.classifier_backward(self.ft, True, w1, w2, w3, self.h1, self.h2, self.d_logits, self.clip,
                                 scratch=self.cls_scratch, grads=cls_grads, d_x=self.d_ft)
-        lib.ft_backward_weight(self.d_ft, self.act, self.F, d_weight=g["input.weight"], d_bias=g["input.bias"])
-        lib.ft_backward_values(self.d_ft, p["input.weight"], self.act, self.P, dst=self.d_conv_out)
+        if self.use_bits:
+            lib.ftb_backward_weight(self.d_ft, self.bits, d_weight=g["input.weight"], d_bias=g["input.bias"])
+            lib.ftb_backward_values(self.d_ft, p["input.weight"], self.bits, dst=self.d_conv_out)
+        else:
+            lib.ft_backward_weight(self.d_ft, self.act, self.F, d_weight=g["input.weight"], d_bias=g["input.bias"])
+            lib.ft_backward_values(self.d_ft, p["input.weight"], self.act, self.P, dst=self.d_conv_out)
         lib.ste_conv_backward(self.images, self.conv_out, p["visual_threshold"], self.d_conv_out, self.stride,
                               d_thr=g["visual_threshold"], d_weight=g["conv.weight"], scratch=self.ste_scratch)
 
@@ -284,5 +295,5 @@ class NnueTrainer:
 
     def active_stats(self) -> Tuple[float, int]:
         """(mean, max) active features per image of the last batch -- reads back; not for timed regions."""
-        n = self.act.n.float()
+        n = (self.bits if self.use_bits else self.act).n.float()
         return float(n.mean()), int(n.max())
