@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 2
+#define NNUE_HIP_ABI_VERSION 3
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -125,35 +125,42 @@ int nnue_ft_backward_values(const float* d_out, const float* weight,
                             const int32_t* rows, const int32_t* pos, const int32_t* n, int cap,
                             int B, int F, int L1, float* dst, int dst_ld, nnue_stream_t stream);
 
-/* ---- FeatureTransformer for binary grid features: bit masks + LDS-staged tiles ---------------
+/* ---- FeatureTransformer for binary grid features: bit masks, tile lists, LDS-staged tiles ---------
  *
  * Inside NNUE.forward the feature values are exactly {0,1} and the ids ascend (nnue.py:590-635), so
- * the act list collapses to bit masks:
+ * the act list collapses to
  *     maskW[b*pw64 + w]  uint64  bit (p & 63) of word p >> 6 = flat position p of sample b is active
  *     maskT[f*bw64 + w]  uint64  bit (b & 63) of word b >> 6 = sample b selects table row f (f < F-1: its
  *                                own position; f = F-1: sink[b] != 0; f = F: every sample -- the bias row)
  *     sink[b]            float   number of active positions >= F-1 (they all clamp to row F-1, nnue.py:701)
- * pw64 and bw64 are even.  The three products below read these instead of id lists; a workgroup stages a
- * tile of the table (or of d_out) in LDS once and all its samples (rows) gather from LDS, so memory-side
- * traffic is the table once per sample tile instead of once per sample.  L1 must be 256, 512 or 1024
- * (nnue_ftb_supported); other widths use the list kernels above. */
+ * (pw64, bw64 even) and, per output and per tile of 128 staged rows, a padded byte list of the rows to add:
+ *     tlW [B][tiles_fwd][128] / tcW [B][tiles_fwd]       sample b   x table-row tile  -> local row indices
+ *     tlT [F+1][tiles_bwd][128] / tcT [F+1][tiles_bwd]   output row x batch tile      -> local sample indices
+ * (ascending, padded with 128 = an all-zero row; entry e at byte ((e>>2)&3)*32 + (e>>4)*4 + (e&3)).
+ * A workgroup stages a tile of the table (or of d_out) in LDS once and all its samples (rows) gather from
+ * LDS, so memory-side traffic is the table once per sample tile instead of once per sample.  L1 must be 256,
+ * 512 or 1024 (nnue_ftb_supported); other widths use the list kernels above. */
 int nnue_ftb_supported(int L1);
+int nnue_ftb_list_tiles(int B, int F, int P, int* tiles_fwd, int* tiles_bwd);
+int64_t nnue_ftb_scratch(int B, int F, int P, int L1); /* bytes for nnue_ftb_forward / _backward_weight */
 
-/* StraightThroughBinary.forward + _to_sparse_features as bit masks (nnue.py:19-25, :590-635).
- * Also writes n[b] = number of active positions.  Bit-exact given conv_out. */
+/* StraightThroughBinary.forward + _to_sparse_features as bit masks and tile lists (nnue.py:19-25,
+ * :590-635).  Also writes n[b] = number of active positions.  Bit-exact given conv_out. */
 int nnue_binarize_bits(const float* conv_out, const float* thr, int B, int fps, int Gh, int Gw, int F,
                        uint64_t* maskW, int pw64, uint64_t* maskT, int bw64, float* sink, int32_t* n,
-                       nnue_stream_t stream);
+                       uint8_t* tlW, uint8_t* tcW, uint8_t* tlT, uint8_t* tcT, nnue_stream_t stream);
 
 /* FeatureTransformer.forward for binary features (nnue.py:686-710):
  *   out[b,:] = bias + sum_{p active, p < min(F-1,P)} weight[p,:] + sink[b] * weight[F-1,:] */
-int nnue_ftb_forward(const float* weight, const float* bias, const uint64_t* maskW, int pw64,
-                     const float* sink, int B, int F, int P, int L1, float* out, nnue_stream_t stream);
+int nnue_ftb_forward(const float* weight, const float* bias, const uint8_t* tlW, const uint8_t* tcW,
+                     const float* sink, int B, int F, int P, int L1, float* out,
+                     void* scratch, int64_t scratch_bytes, nnue_stream_t stream);
 
-/* Its weight/bias gradient (autograd of nnue.py:702-708), rows summed in ascending sample order, no
- * atomics.  Either output may be NULL. */
-int nnue_ftb_backward_weight(const float* d_out, const uint64_t* maskT, int bw64, const float* sink,
-                             int B, int F, int L1, float* d_weight, float* d_bias, nnue_stream_t stream);
+/* Its weight/bias gradient (autograd of nnue.py:702-708), fixed summation order, no atomics.
+ * Either output may be NULL. */
+int nnue_ftb_backward_weight(const float* d_out, const uint8_t* tlT, const uint8_t* tcT, const float* sink,
+                             int B, int F, int P, int L1, float* d_weight, float* d_bias,
+                             void* scratch, int64_t scratch_bytes, nnue_stream_t stream);
 
 /* Its value gradient scattered to the map (autograd of nnue.py:705-707 and :628-633; identity STE :33):
  *   d_conv_out[b,p] = active(b,p) ? < d_out[b,:], weight[min(p,F-1),:] > : 0     for every p < P */

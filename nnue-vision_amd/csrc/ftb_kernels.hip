@@ -1,52 +1,80 @@
 // FeatureTransformer for BINARY grid features, LDS-staged and batch-tiled (gfx950).
 //
 // Inside NNUE.forward the feature values are exactly {0,1} and the ids ascend (nnue.py:590-635), so
-// the act list collapses to bit masks and the three FT products become bit-driven gathers out of LDS:
+// the three FT products become gathers out of LDS tiles driven by bit masks / per-tile byte lists:
 //
 //   forward        out[b]  = bias + sum_{p active, p < F-1} W[p] + sink[b] * W[F-1]      (nnue.py:686-710)
 //   weight grad    dW[f]   = sum_{b: bit(b,f)} dOut[b] ; dW[F-1] = sum_b sink[b]*dOut[b] ; db = sum_b dOut[b]
 //   value grad     dX[b,p] = bit(b,p) ? <dOut[b], W[min(p,F-1)]> : 0                      (= d conv_out)
 //
 // where sink[b] counts the active ids >= F-1 (the clamp of nnue.py:701).  Instead of every sample
-// re-reading its ~400 table rows from L2/HBM (gather kernels in ft_kernels.hip: 854 MB of L2 traffic per
-// launch at the CIFAR shapes), a workgroup stages a tile of the table (or of dOut) in LDS ONCE and all of
-// its samples (rows) gather from there: memory-side traffic drops by the sample-tile factor and the
-// inner loop runs at LDS bandwidth.  Accumulation order per output element is ascending row / sample
-// order: results are bitwise reproducible and equal the list kernels' up to the sink term.
+// re-reading its ~400 table rows from L2/HBM (the list kernels in ft_kernels.hip), a workgroup stages a
+// tile of the table (or of dOut) in LDS ONCE and all of its samples (rows) gather from there: memory-side
+// traffic drops by the sample-tile factor and the inner loop runs out of LDS.
 //
-// Layouts:  maskW [B][pw64]  u64, bit p of sample b  (flat position bits, p < P; pw64 even)
-//           maskT [F+1][bw64] u64, bit b of table row f; row F-1 = (sink[b] != 0), row F = all samples
-//           sink  [B] float
+// Layouts (include/nnue_hip.h):
+//   maskW [B][pw64] u64      bit p of sample b (flat position bits)
+//   maskT [F+1][bw64] u64    bit b of table row f; row F-1 = (sink[b] != 0), row F = every sample (bias)
+//   sink  [B] float
+//   tile lists  tl [R][NT][128] u8 + tc [R][NT] u8: for output r and tile t (128 staged rows) the local
+//               indices (0..127) of the staged rows to add, ascending, padded with 128 (= an all-zero LDS
+//               row).  Entry e sits at byte ((e>>2)&3)*32 + (e>>4)*4 + (e&3): lane group g of a wave reads
+//               its entries {16c + 4g + k} as 32 contiguous bytes.
+//     forward lists  : R = B samples,      tiles over table rows   (tlW / tcW)
+//     backward lists : R = F + 1 outputs,  tiles over batch samples (tlT / tcT)
 #include "common.h"
 
 namespace {
 
 using u64 = unsigned long long;
 
-constexpr int kTC = 64;    // columns per workgroup: 16 lanes x float4, 4 lane groups per wave
-constexpr int kRT = 128;   // staged rows per LDS tile (two 64-bit mask words)
-constexpr int kTileFloats = kRT * kTC + kTC;  // + one all-zero row that exhausted lanes read
+constexpr int kTC = 64;                       // columns per workgroup: 16 lanes x float4
+constexpr int kRT = 128;                      // staged rows per LDS tile
+constexpr int kTileFloats = kRT * kTC + kTC;  // + the all-zero row (index kRT)
+constexpr int kWaves = 8;                     // waves per gather workgroup
 
-// ------------------------------------------------------------------ bit masks from conv_out
-// per sample: position words, active count, sink count
+__device__ __forceinline__ int list_pos(int e) { return ((e >> 2) & 3) * 32 + (e >> 4) * 4 + (e & 3); }
+
+// Writes the tile list of one (output, tile) from its two 64-bit membership words.  One wave; lane = bit.
+__device__ __forceinline__ void emit_tile_list(u64 m0, u64 m1, int lane, unsigned char* __restrict__ lst,
+                                               unsigned char* __restrict__ cnt_out) {
+  const u64 lt = (1ull << lane) - 1ull;
+  const int c0 = __popcll(m0), cnt = c0 + __popcll(m1);
+  if ((m0 >> lane) & 1ull) lst[list_pos(__popcll(m0 & lt))] = (unsigned char)lane;
+  if ((m1 >> lane) & 1ull) lst[list_pos(c0 + __popcll(m1 & lt))] = (unsigned char)(64 + lane);
+  if (lane >= cnt) lst[list_pos(lane)] = (unsigned char)kRT;  // padding -> zero row
+  if (64 + lane >= cnt) lst[list_pos(64 + lane)] = (unsigned char)kRT;
+  if (lane == 0) *cnt_out = (unsigned char)cnt;
+}
+
+// ------------------------------------------------------------------ bit masks + lists from conv_out
+// One workgroup per sample; wave w takes position tiles w, w+4, ... (128 positions = two ballots).
 __global__ __launch_bounds__(256) void bits_rows_kernel(const float* __restrict__ conv_out,
                                                         const float* __restrict__ thr, int G, int P, int F,
                                                         u64* __restrict__ maskW, int pw64, float* __restrict__ sink,
-                                                        int* __restrict__ n) {
+                                                        int* __restrict__ n, unsigned char* __restrict__ tlW,
+                                                        unsigned char* __restrict__ tcW, int ntW) {
   __shared__ int cnt_s[4], sink_s[4];
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* __restrict__ x = conv_out + (size_t)b * P;
+  const int direct = (F - 1 < P) ? F - 1 : P;  // positions with a table row of their own
   int cnt = 0, snk = 0;
-  for (int p0 = 0; p0 < pw64 * 64; p0 += 256) {
-    const int p = p0 + tid;
-    const bool on = (p < P) && (x[p] > thr[p / G]);
-    const u64 m = __ballot(on);
-    const u64 ms = __ballot(on && p >= F - 1);
-    const int word = p0 / 64 + wave;
-    if (lane == 0 && word < pw64) maskW[(size_t)b * pw64 + word] = m;
-    cnt += __popcll(m);
-    snk += __popcll(ms);
+  for (int t = wave; t < pw64 / 2; t += 4) {
+    const int p0 = t * 128 + lane, p1 = p0 + 64;
+    const bool on0 = (p0 < P) && (x[p0] > thr[p0 / G]);
+    const bool on1 = (p1 < P) && (x[p1] > thr[p1 / G]);
+    const u64 m0 = __ballot(on0), m1 = __ballot(on1);
+    if (lane == 0) {
+      maskW[(size_t)b * pw64 + 2 * t] = m0;
+      maskW[(size_t)b * pw64 + 2 * t + 1] = m1;
+    }
+    cnt += __popcll(m0) + __popcll(m1);
+    snk += __popcll(__ballot(on0 && p0 >= F - 1)) + __popcll(__ballot(on1 && p1 >= F - 1));
+    if (t < ntW) {
+      const u64 d0 = __ballot(on0 && p0 < direct), d1 = __ballot(on1 && p1 < direct);
+      emit_tile_list(d0, d1, lane, tlW + ((size_t)b * ntW + t) * kRT, tcW + (size_t)b * ntW + t);
+    }
   }
   if (lane == 0) {
     cnt_s[wave] = cnt;
@@ -59,18 +87,21 @@ __global__ __launch_bounds__(256) void bits_rows_kernel(const float* __restrict_
   }
 }
 
-// transposed words: 64 table rows x 64 samples per workgroup through an LDS byte tile + ballots
+// Transposed membership: 16 table rows x 128 samples per workgroup through an LDS byte tile + ballots.
+constexpr int kTrRows = 16;
 __global__ __launch_bounds__(256) void bits_transpose_kernel(const float* __restrict__ conv_out,
                                                              const float* __restrict__ thr,
                                                              const float* __restrict__ sink, int B, int G, int P,
-                                                             int F, u64* __restrict__ maskT, int bw64) {
-  __shared__ unsigned char tile[64][68];
-  const int f0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+                                                             int F, u64* __restrict__ maskT, int bw64,
+                                                             unsigned char* __restrict__ tlT,
+                                                             unsigned char* __restrict__ tcT, int ntT) {
+  __shared__ unsigned char tile[128][kTrRows + 4];
+  const int f0 = blockIdx.x * kTrRows, b0 = blockIdx.y * 128;
+  const int tx = threadIdx.x & (kTrRows - 1), ty = threadIdx.x / kTrRows;  // 16 rows x 16 sample lanes
   const int f = f0 + tx;
-  const int direct = (F - 1 < P) ? F - 1 : P;  // rows with a position bit of their own
+  const int direct = (F - 1 < P) ? F - 1 : P;
   const float t = (f < direct) ? thr[f / G] : 0.0f;
-  for (int j = ty; j < 64; j += 4) {
+  for (int j = ty; j < 128; j += 256 / kTrRows) {
     const int b = b0 + j;
     bool on = false;
     if (b < B) {
@@ -81,55 +112,63 @@ __global__ __launch_bounds__(256) void bits_transpose_kernel(const float* __rest
     tile[j][tx] = on ? 1 : 0;
   }
   __syncthreads();
-  for (int j = ty; j < 64; j += 4) {
-    const u64 m = __ballot(tile[tx][j] != 0);  // lane = sample
-    if (tx == 0 && f0 + j <= F) maskT[(size_t)(f0 + j) * bw64 + blockIdx.y] = m;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = wave; j < kTrRows; j += 4) {
+    const int fo = f0 + j;
+    const u64 m0 = __ballot(tile[lane][j] != 0), m1 = __ballot(tile[64 + lane][j] != 0);  // lane = sample
+    if (fo > F) continue;  // wave-uniform
+    if (lane == 0) {
+      maskT[(size_t)fo * bw64 + 2 * blockIdx.y] = m0;
+      maskT[(size_t)fo * bw64 + 2 * blockIdx.y + 1] = m1;
+    }
+    emit_tile_list(m0, m1, lane, tlT + ((size_t)fo * ntT + blockIdx.y) * kRT, tcT + (size_t)fo * ntT + blockIdx.y);
   }
 }
 
-// ------------------------------------------------------------------ bit-driven gather out of LDS
-// MODE 0 (forward):     outputs = samples,    gathered rows = table rows, masks = maskW, bias + valued sink row
-// MODE 1 (weight grad): outputs = table rows, gathered rows = d_out rows, masks = maskT, row F-1 valued by sink[]
-// Workgroup = 4 waves; a wave = 4 lane groups of 16 lanes (64 columns as float4), each group owns SG
-// outputs.  The gathered matrix streams through two 32 KB LDS tiles (register-staged: loads for tile
-// t+1 are issued before tile t is consumed).  Per tile and output, the set bits of two mask words
-// select the LDS rows to add; groups that run out of bits read an all-zero row, so the loop has no
-// divergence.
-template <int SG, int MODE>
-__global__ __launch_bounds__(256) void ftb_gather_kernel(const float* __restrict__ src,      // [n_src][L1]
-                                                         const float* __restrict__ bias,     // MODE 0
-                                                         const u64* __restrict__ mask, int mw64,
-                                                         const float* __restrict__ sink,     // [B]
-                                                         int n_out, int n_src, int sink_row, int L1,
-                                                         float* __restrict__ out,            // [n_out][L1] (MODE 1: d_weight)
-                                                         float* __restrict__ out_extra) {    // MODE 1: d_bias
+// ------------------------------------------------------------------ list-driven gather out of LDS
+// MODE 0 (forward):     outputs = samples,    staged rows = table rows, lists tlW; bias + valued sink row
+// MODE 1 (weight grad): outputs = table rows + bias row, staged rows = d_out rows, lists tlT; row F-1 valued by sink[]
+//
+// Workgroup = 8 waves x SW outputs each, 64 columns (grid.y), a slice of the tiles (grid.z).  The staged
+// matrix streams through two 32 KB LDS buffers (loads for tile t+1 are issued before tile t is consumed).
+// Control flow is wave-uniform: a wave works on ONE output at a time; its four 16-lane groups fetch four
+// DIFFERENT staged rows with one ds_read_b128 (1 KiB), indices coming from list bytes that were loaded
+// one tile ahead.  Each lane group therefore holds a partial sum over every 4th-of-16 entries; the four
+// partials are combined in a fixed order at the end.
+template <int SW, int MODE>
+__global__ __launch_bounds__(512) void ftb_gather_kernel(const float* __restrict__ src,   // [n_src][L1]
+                                                         const float* __restrict__ bias,  // MODE 0
+                                                         const unsigned char* __restrict__ tl,
+                                                         const unsigned char* __restrict__ tc, int nt,
+                                                         const float* __restrict__ sink, int n_out, int n_src,
+                                                         int sink_row, int L1, int tiles_per_split,
+                                                         float* __restrict__ out, float* __restrict__ out_extra,
+                                                         float* __restrict__ slabs) {
   __shared__ __attribute__((aligned(16))) float tile[2][kTileFloats];
-  __shared__ float coef_t[2][kRT];  // MODE 1: sink[] of the staged samples
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float coef_t[2][kRT + 1];  // MODE 1: sink[] of the staged samples (+ 0 for the zero row)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = lane >> 4, l16 = lane & 15;
-  const int c0 = blockIdx.y * kTC + l16 * 4;
-  const int o0 = blockIdx.x * (16 * SG) + (wave * 4 + grp) * SG;
+  const int col = blockIdx.y * kTC + l16 * 4;
+  const int o0 = (blockIdx.x * kWaves + wave) * SW;
+  const int t_lo = blockIdx.z * tiles_per_split;
+  const int t_hi = min(nt, t_lo + tiles_per_split);
 
-  float4 acc[SG];
-  bool ok[SG];
+  float4 acc[SW];
 #pragma unroll
-  for (int s = 0; s < SG; ++s) {
-    ok[s] = o0 + s < n_out;
-    acc[s] = (MODE == 0) ? *reinterpret_cast<const float4*>(bias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < SW; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < 2 * (kTC / 4)) {
+    reinterpret_cast<float4*>(&tile[tid / (kTC / 4)][kRT * kTC])[tid % (kTC / 4)] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 2) coef_t[tid][kRT] = 0.f;
   }
-  if (tid < 2 * (kTC / 4)) {  // the zero rows
-    float4* z = reinterpret_cast<float4*>(&tile[tid / (kTC / 4)][kRT * kTC]);
-    z[tid % (kTC / 4)] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  const int ntiles = (n_src + kRT - 1) / kRT;
-  const int srow = tid >> 4, scol = (tid & 15) * 4;  // staging role: 16 rows x 64 columns per pass, 8 passes
+  const int srow = tid >> 4, scol = (tid & 15) * 4;  // staging role: 32 rows x 64 columns per pass, 4 passes
 
-  float4 st[8];
+  float4 st[4];
   float st_coef = 0.f;
   auto stage_load = [&](int t) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = t * kRT + srow + 16 * i;
+    for (int i = 0; i < 4; ++i) {
+      const int r = t * kRT + srow + 32 * i;
       st[i] = (r < n_src) ? *reinterpret_cast<const float4*>(src + (size_t)r * L1 + blockIdx.y * kTC + scol)
                           : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -137,257 +176,341 @@ __global__ __launch_bounds__(256) void ftb_gather_kernel(const float* __restrict
   };
   auto stage_store = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(&tile[buf][(srow + 16 * i) * kTC + scol]) = st[i];
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&tile[buf][(srow + 32 * i) * kTC + scol]) = st[i];
     if (MODE == 1 && tid < kRT) coef_t[buf][tid] = st_coef;
   };
-  auto load_words = [&](int t, u64 (&w)[SG][2]) {
+  // list bytes of this lane group for output s, tile t: 2 x uint4 = its 32 entries (8 chunks x 4)
+  auto load_list = [&](int t, uint4 (&lo)[SW], uint4 (&hi)[SW], int (&cnt)[SW]) {
 #pragma unroll
-    for (int s = 0; s < SG; ++s)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int word = 2 * t + h;
-        u64 m = (ok[s] && word < mw64) ? mask[(size_t)(o0 + s) * mw64 + word] : 0ull;
-        const int base = word * 64;  // rows this word covers: [base, base + 64)
-        if (base + 64 > n_src) m = (base >= n_src) ? 0ull : (m & ((1ull << (n_src - base)) - 1ull));
-        w[s][h] = m;
+    for (int s = 0; s < SW; ++s) {
+      const int o = o0 + s;
+      if (o < n_out) {
+        const unsigned char* p = tl + ((size_t)o * nt + t) * kRT + grp * 32;
+        lo[s] = *reinterpret_cast<const uint4*>(p);
+        hi[s] = *reinterpret_cast<const uint4*>(p + 16);
+        cnt[s] = tc[(size_t)o * nt + t];
+      } else {
+        cnt[s] = 0;
       }
+    }
   };
 
-  u64 mw[SG][2], nw[SG][2];
-  if (ntiles > 0) {
-    stage_load(0);
-    load_words(0, mw);
+  uint4 lo[SW], hi[SW], nlo[SW], nhi[SW];
+  int cnt[SW], ncnt[SW];
+  if (t_lo < t_hi) {
+    stage_load(t_lo);
+    load_list(t_lo, lo, hi, cnt);
     stage_store(0);
   }
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < ntiles) {
+  for (int t = t_lo; t < t_hi; ++t) {
+    const int buf = (t - t_lo) & 1;
+    if (t + 1 < t_hi) {
       stage_load(t + 1);
-      load_words(t + 1, nw);
+      load_list(t + 1, nlo, nhi, ncnt);
     }
-    const float* __restrict__ tb = &tile[buf][0];
+    const char* __restrict__ tb = reinterpret_cast<const char*>(&tile[buf][0]) + l16 * 16;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      u64 m[SG];
-      u64 any = 0;
+    for (int s = 0; s < SW; ++s) {
+      const int c = __builtin_amdgcn_readfirstlane(cnt[s]);
+      const bool valued = (MODE == 1) && (o0 + s == sink_row);  // wave-uniform
+      const unsigned words[8] = {lo[s].x, lo[s].y, lo[s].z, lo[s].w, hi[s].x, hi[s].y, hi[s].z, hi[s].w};
 #pragma unroll
-      for (int s = 0; s < SG; ++s) {
-        m[s] = mw[s][h];
-        any |= m[s];
-      }
-      while (__any(any != 0)) {
-        constexpr int U = (SG >= 4) ? 1 : (SG == 2 ? 2 : 4);  // rows per output per iteration: 4 LDS reads in flight
-        float4 v[SG][U];
-        float c[SG][U];
-#pragma unroll
-        for (int s = 0; s < SG; ++s)
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const bool has = m[s] != 0;
-            const int j = has ? (h * 64 + __builtin_ctzll(m[s])) : kRT;  // kRT = the zero row
-            m[s] &= m[s] - 1;
-            v[s][u] = *reinterpret_cast<const float4*>(tb + j * kTC + l16 * 4);
-            c[s][u] = 1.0f;
-            if (MODE == 1 && o0 + s == sink_row) c[s][u] = has ? coef_t[buf][j] : 0.f;
-          }
-        any = 0;
-#pragma unroll
-        for (int s = 0; s < SG; ++s) {
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            acc[s].x = fmaf(c[s][u], v[s][u].x, acc[s].x);
-            acc[s].y = fmaf(c[s][u], v[s][u].y, acc[s].y);
-            acc[s].z = fmaf(c[s][u], v[s][u].z, acc[s].z);
-            acc[s].w = fmaf(c[s][u], v[s][u].w, acc[s].w);
-          }
-          any |= m[s];
+      for (int ch = 0; ch < 8; ++ch) {
+        if (ch * 16 >= c) break;  // wave-uniform
+        const unsigned e = words[ch];
+        const unsigned j0 = e & 0xffu, j1 = (e >> 8) & 0xffu, j2 = (e >> 16) & 0xffu, j3 = e >> 24;
+        const float4 v0 = *reinterpret_cast<const float4*>(tb + j0 * (kTC * 4));
+        const float4 v1 = *reinterpret_cast<const float4*>(tb + j1 * (kTC * 4));
+        const float4 v2 = *reinterpret_cast<const float4*>(tb + j2 * (kTC * 4));
+        const float4 v3 = *reinterpret_cast<const float4*>(tb + j3 * (kTC * 4));
+        if (!valued) {
+          acc[s].x += v0.x; acc[s].y += v0.y; acc[s].z += v0.z; acc[s].w += v0.w;
+          acc[s].x += v1.x; acc[s].y += v1.y; acc[s].z += v1.z; acc[s].w += v1.w;
+          acc[s].x += v2.x; acc[s].y += v2.y; acc[s].z += v2.z; acc[s].w += v2.w;
+          acc[s].x += v3.x; acc[s].y += v3.y; acc[s].z += v3.z; acc[s].w += v3.w;
+        } else {
+          const float c0 = coef_t[buf][j0], c1 = coef_t[buf][j1], c2 = coef_t[buf][j2], c3 = coef_t[buf][j3];
+          acc[s].x = fmaf(c0, v0.x, acc[s].x); acc[s].y = fmaf(c0, v0.y, acc[s].y); acc[s].z = fmaf(c0, v0.z, acc[s].z); acc[s].w = fmaf(c0, v0.w, acc[s].w);
+          acc[s].x = fmaf(c1, v1.x, acc[s].x); acc[s].y = fmaf(c1, v1.y, acc[s].y); acc[s].z = fmaf(c1, v1.z, acc[s].z); acc[s].w = fmaf(c1, v1.w, acc[s].w);
+          acc[s].x = fmaf(c2, v2.x, acc[s].x); acc[s].y = fmaf(c2, v2.y, acc[s].y); acc[s].z = fmaf(c2, v2.z, acc[s].z); acc[s].w = fmaf(c2, v2.w, acc[s].w);
+          acc[s].x = fmaf(c3, v3.x, acc[s].x); acc[s].y = fmaf(c3, v3.y, acc[s].y); acc[s].z = fmaf(c3, v3.z, acc[s].z); acc[s].w = fmaf(c3, v3.w, acc[s].w);
         }
       }
     }
-    if (t + 1 < ntiles) stage_store(buf ^ 1);
+    if (t + 1 < t_hi) stage_store(buf ^ 1);
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < SG; ++s) {
-      mw[s][0] = nw[s][0];
-      mw[s][1] = nw[s][1];
+    for (int s = 0; s < SW; ++s) {
+      lo[s] = nlo[s];
+      hi[s] = nhi[s];
+      cnt[s] = ncnt[s];
     }
   }
+  // combine the four lane-group partials (fixed order), then lanes 0..15 hold the 64-column result
 #pragma unroll
-  for (int s = 0; s < SG; ++s) {
-    if (!ok[s]) continue;
+  for (int s = 0; s < SW; ++s) {
+    float4 a = acc[s];
+    a.x += __shfl_xor(a.x, 16); a.y += __shfl_xor(a.y, 16); a.z += __shfl_xor(a.z, 16); a.w += __shfl_xor(a.w, 16);
+    a.x += __shfl_xor(a.x, 32); a.y += __shfl_xor(a.y, 32); a.z += __shfl_xor(a.z, 32); a.w += __shfl_xor(a.w, 32);
     const int o = o0 + s;
+    if (o >= n_out || grp != 0) continue;
+    if (slabs != nullptr) {  // tiles were split over grid.z: partial sums, finished by ftb_finish_kernel
+      *reinterpret_cast<float4*>(slabs + ((size_t)blockIdx.z * n_out + o) * L1 + col) = a;
+      continue;
+    }
     if (MODE == 0) {
+      const float4 bv = *reinterpret_cast<const float4*>(bias + col);
+      a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
       if (sink_row >= 0) {  // folded ids: sink[b] copies of table row F-1
         const float sv = sink[o];
         if (sv != 0.f) {
-          const float4 w = *reinterpret_cast<const float4*>(src + (size_t)sink_row * L1 + c0);
-          acc[s].x = fmaf(sv, w.x, acc[s].x);
-          acc[s].y = fmaf(sv, w.y, acc[s].y);
-          acc[s].z = fmaf(sv, w.z, acc[s].z);
-          acc[s].w = fmaf(sv, w.w, acc[s].w);
+          const float4 w = *reinterpret_cast<const float4*>(src + (size_t)sink_row * L1 + col);
+          a.x = fmaf(sv, w.x, a.x); a.y = fmaf(sv, w.y, a.y); a.z = fmaf(sv, w.z, a.z); a.w = fmaf(sv, w.w, a.w);
         }
       }
-      *reinterpret_cast<float4*>(out + (size_t)o * L1 + c0) = acc[s];
+      *reinterpret_cast<float4*>(out + (size_t)o * L1 + col) = a;
     } else {
       float* dst = (o == n_out - 1) ? out_extra : out;  // last output row = bias gradient
-      if (dst != nullptr) *reinterpret_cast<float4*>(dst + (o == n_out - 1 ? (size_t)0 : (size_t)o * L1) + c0) = acc[s];
+      if (dst != nullptr) *reinterpret_cast<float4*>(dst + (o == n_out - 1 ? (size_t)0 : (size_t)o * L1) + col) = a;
     }
   }
 }
 
+// Sums the split slabs in order and applies what the unsplit kernel does in its epilogue.
+template <int MODE>
+__global__ __launch_bounds__(256) void ftb_finish_kernel(const float* __restrict__ slabs, int splits, int n_out, int L1,
+                                                         const float* __restrict__ src, const float* __restrict__ bias,
+                                                         const float* __restrict__ sink, int sink_row,
+                                                         float* __restrict__ out, float* __restrict__ out_extra) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // float4 index
+  const int q = L1 / 4;
+  if (i >= (long long)n_out * q) return;
+  const int o = (int)(i / q), col = (int)(i - (long long)o * q) * 4;
+  float4 a = *reinterpret_cast<const float4*>(slabs + (size_t)o * L1 + col);
+  for (int s = 1; s < splits; ++s) {
+    const float4 v = *reinterpret_cast<const float4*>(slabs + ((size_t)s * n_out + o) * L1 + col);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  if (MODE == 0) {
+    const float4 bv = *reinterpret_cast<const float4*>(bias + col);
+    a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
+    if (sink_row >= 0) {
+      const float sv = sink[o];
+      if (sv != 0.f) {
+        const float4 w = *reinterpret_cast<const float4*>(src + (size_t)sink_row * L1 + col);
+        a.x = fmaf(sv, w.x, a.x); a.y = fmaf(sv, w.y, a.y); a.z = fmaf(sv, w.z, a.z); a.w = fmaf(sv, w.w, a.w);
+      }
+    }
+    *reinterpret_cast<float4*>(out + (size_t)o * L1 + col) = a;
+  } else {
+    float* dst = (o == n_out - 1) ? out_extra : out;
+    if (dst != nullptr) *reinterpret_cast<float4*>(dst + (o == n_out - 1 ? (size_t)0 : (size_t)o * L1) + col) = a;
+  }
+}
+
 // ------------------------------------------------------------------ value gradient
-// Workgroup = (sample tile) x (32 table rows).  The 32 rows (32 x L1 floats, 128 KB at L1 = 1024) are
+// Workgroup (8 waves) = (sample tile) x (RB table rows).  The rows (RB x L1 floats, 64 KB at L1 = 1024) are
 // staged in LDS once; each wave then walks its samples: d_out[b] sits in registers (prefetched one sample
-// ahead), the set bits of the sample's 32-bit mask slice pick LDS rows, 16 dot products at a time are
-// transposed-and-reduced across the wave with a butterfly, and ranks map them back to bit positions, so
-// the 32 outputs leave as ONE coalesced 128-byte store (zeros included: no separate zero fill).
+// ahead together with the sample's mask word), the set bits of the 16-bit mask slice pick LDS rows, the dot
+// products are transposed-and-reduced across the wave with a butterfly, and ranks map them back to bit
+// positions, so the RB outputs leave as ONE coalesced store (zeros included: no separate zero fill).
 template <int S>
-__global__ __launch_bounds__(256) void ftb_values_kernel(const float* __restrict__ d_out,
+__global__ __launch_bounds__(512) void ftb_values_kernel(const float* __restrict__ d_out,
                                                          const float* __restrict__ W,
                                                          const u64* __restrict__ maskW, int pw64, int B, int F,
                                                          int P, int samples_per_block, float* __restrict__ dst) {
   constexpr int L1 = 256 * S;
-  __shared__ __attribute__((aligned(16))) float rows[32 * L1];
+  constexpr int RB = 16;  // rows per workgroup = one butterfly round
+  __shared__ __attribute__((aligned(16))) float rows[RB * L1];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool has_sink = F - 1 < P;                   // ids >= F-1 exist and fold into row F-1
-  const int p_lim = has_sink ? F - 1 : P;            // positions below p_lim have a table row of their own
-  const int r_last = has_sink ? F - 1 : P - 1;       // highest row that can be referenced
-  const int r0 = blockIdx.y * 32;
-  const int nrows = min(32, r_last + 1 - r0);
-  for (int i = tid; i < nrows * (L1 / 4); i += 256) {
+  const bool has_sink = F - 1 < P;              // ids >= F-1 exist and fold into row F-1
+  const int p_lim = has_sink ? F - 1 : P;       // positions below p_lim have a table row of their own
+  const int r_last = has_sink ? F - 1 : P - 1;  // highest row that can be referenced
+  const int r0 = blockIdx.y * RB;
+  const int nrows = min(RB, r_last + 1 - r0);
+  for (int i = tid; i < nrows * (L1 / 4); i += 512) {
     const int r = i / (L1 / 4), c4 = i - r * (L1 / 4);
     reinterpret_cast<float4*>(rows)[i] = *reinterpret_cast<const float4*>(W + (size_t)(r0 + r) * L1 + c4 * 4);
   }
   __syncthreads();
-  const bool sink_block = has_sink && (F - 1 >= r0) && (F - 1 < r0 + 32);
+  const bool sink_block = has_sink && (F - 1 >= r0) && (F - 1 < r0 + RB);
   const int b_lo = blockIdx.x * samples_per_block;
   const int b_hi = min(B, b_lo + samples_per_block);
-  const int nd = p_lim - r0;  // direct positions in this block's 32-wide slice
-  const unsigned keep = nd >= 32 ? 0xffffffffu : (nd <= 0 ? 0u : ((1u << nd) - 1u));
+  const int nd = p_lim - r0;  // direct positions in this block's RB-wide slice
+  const unsigned keep = nd >= RB ? ((1u << RB) - 1u) : (nd <= 0 ? 0u : ((1u << nd) - 1u));
   const float* __restrict__ rl = rows + lane * 4;
+  const int L = lane & (RB - 1);
 
   float4 g[S], gn[S];
+  u64 word = 0, wordn = 0;
   int b = b_lo + wave;
   if (b < b_hi) {
 #pragma unroll
     for (int s = 0; s < S; ++s) g[s] = *reinterpret_cast<const float4*>(d_out + (size_t)b * L1 + s * 256 + lane * 4);
+    word = maskW[(size_t)b * pw64 + (r0 >> 6)];
   }
-  for (; b < b_hi; b += 4) {
-    const int bn = b + 4;
+  for (; b < b_hi; b += kWaves) {
+    const int bn = b + kWaves;
     if (bn < b_hi) {
 #pragma unroll
       for (int s = 0; s < S; ++s) gn[s] = *reinterpret_cast<const float4*>(d_out + (size_t)bn * L1 + s * 256 + lane * 4);
+      wordn = maskW[(size_t)bn * pw64 + (r0 >> 6)];
     }
-    const u64 word = maskW[(size_t)b * pw64 + (r0 >> 6)];
     const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(word >> (r0 & 63))) & keep;
-    const int L = lane & 31;
-    const int rank = __popc(m & ((1u << L) - 1u));
-    const bool bit_mine = (m >> L) & 1u;
-    float res = 0.f;
+    float p[RB];
     unsigned mm = m;
-    for (int grp = 0; mm != 0; ++grp) {  // 16 set bits per round (at most two rounds)
-      float p[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        float a = 0.f;
-        if (mm != 0) {  // wave-uniform
-          const int j = __builtin_ctz(mm);
-          mm &= mm - 1;
-          const float* __restrict__ wr = rl + j * L1;
+    for (int u = 0; u < RB; ++u) {
+      float a = 0.f;
+      if (mm != 0) {  // wave-uniform
+        const int j = __builtin_ctz(mm);
+        mm &= mm - 1;
+        const float* __restrict__ wr = rl + j * L1;
+        float part[S];
 #pragma unroll
-          for (int s = 0; s < S; ++s) {
-            const float4 v = *reinterpret_cast<const float4*>(wr + s * 256);
-            a = fmaf(v.x, g[s].x, a);
-            a = fmaf(v.y, g[s].y, a);
-            a = fmaf(v.z, g[s].z, a);
-            a = fmaf(v.w, g[s].w, a);
-          }
+        for (int s = 0; s < S; ++s) {
+          const float4 v = *reinterpret_cast<const float4*>(wr + s * 256);
+          part[s] = fmaf(v.w, g[s].w, fmaf(v.z, g[s].z, fmaf(v.y, g[s].y, v.x * g[s].x)));
         }
-        p[u] = a;
-      }
+        a = part[0];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const bool hi = lane & 8;
-        const float keepv = hi ? p[u + 8] : p[u], send = hi ? p[u] : p[u + 8];
-        p[u] = keepv + __shfl_xor(send, 8);
+        for (int s = 1; s < S; ++s) a += part[s];
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool hi = lane & 4;
-        const float keepv = hi ? p[u + 4] : p[u], send = hi ? p[u] : p[u + 4];
-        p[u] = keepv + __shfl_xor(send, 4);
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const bool hi = lane & 2;
-        const float keepv = hi ? p[u + 2] : p[u], send = hi ? p[u] : p[u + 2];
-        p[u] = keepv + __shfl_xor(send, 2);
-      }
-      {
-        const bool hi = lane & 1;
-        const float keepv = hi ? p[1] : p[0], send = hi ? p[0] : p[1];
-        p[0] = keepv + __shfl_xor(send, 1);
-      }
-      float tot = p[0];
-      tot += __shfl_xor(tot, 16);
-      tot += __shfl_xor(tot, 32);  // every lane: dot product of entry (lane & 15) of this round
-      const float v = __shfl(tot, rank & 15);
-      if (bit_mine && (rank >> 4) == grp) res = v;
+      p[u] = a;
     }
-    if (lane < 32 && lane < nd) dst[(size_t)b * P + r0 + lane] = res;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool hi = lane & 8;
+      const float keepv = hi ? p[u + 8] : p[u], send = hi ? p[u] : p[u + 8];
+      p[u] = keepv + __shfl_xor(send, 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool hi = lane & 4;
+      const float keepv = hi ? p[u + 4] : p[u], send = hi ? p[u] : p[u + 4];
+      p[u] = keepv + __shfl_xor(send, 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const bool hi = lane & 2;
+      const float keepv = hi ? p[u + 2] : p[u], send = hi ? p[u] : p[u + 2];
+      p[u] = keepv + __shfl_xor(send, 2);
+    }
+    {
+      const bool hi = lane & 1;
+      const float keepv = hi ? p[1] : p[0], send = hi ? p[0] : p[1];
+      p[0] = keepv + __shfl_xor(send, 1);
+    }
+    float tot = p[0];
+    tot += __shfl_xor(tot, 16);
+    tot += __shfl_xor(tot, 32);  // every lane: dot product of the (lane & 15)-th set bit
+    const int rank = __popc(m & ((1u << L) - 1u));
+    const float v = __shfl(tot, rank);
+    const float res = ((m >> L) & 1u) ? v : 0.f;
+    if (lane < RB && lane < nd) dst[(size_t)b * P + r0 + lane] = res;
     if (sink_block) {  // every active id >= F-1 receives <d_out[b], W[F-1]>
       const float* __restrict__ wr = rl + (F - 1 - r0) * L1;
       float a = 0.f;
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         const float4 v = *reinterpret_cast<const float4*>(wr + s * 256);
-        a = fmaf(v.x, g[s].x, a);
-        a = fmaf(v.y, g[s].y, a);
-        a = fmaf(v.z, g[s].z, a);
-        a = fmaf(v.w, g[s].w, a);
+        a += fmaf(v.w, g[s].w, fmaf(v.z, g[s].z, fmaf(v.y, g[s].y, v.x * g[s].x)));
       }
 #pragma unroll
       for (int sft = 32; sft >= 1; sft >>= 1) a += __shfl_xor(a, sft);
-      for (int p = F - 1 + lane; p < P; p += 64) {
-        const bool on = (maskW[(size_t)b * pw64 + (p >> 6)] >> (p & 63)) & 1ull;
-        dst[(size_t)b * P + p] = on ? a : 0.f;
+      for (int pp = F - 1 + lane; pp < P; pp += 64) {
+        const bool on = (maskW[(size_t)b * pw64 + (pp >> 6)] >> (pp & 63)) & 1ull;
+        dst[(size_t)b * P + pp] = on ? a : 0.f;
       }
     }
 #pragma unroll
     for (int s = 0; s < S; ++s) g[s] = gn[s];
+    word = wordn;
   }
 }
 
-int pick_sg(int n_out, int col_tiles) {
-  // largest SG (outputs per lane group) that still leaves >= 256 workgroups; more outputs per staged tile =
-  // less staging traffic per output
-  for (int sg = 4; sg > 1; sg >>= 1)
-    if ((long long)((n_out + 16 * sg - 1) / (16 * sg)) * col_tiles >= 256) return sg;
-  return 1;
+struct GatherPlan {
+  int sw, splits, tiles_per_split;
+};
+
+GatherPlan plan_gather(int n_out, int nt, int col_tiles) {
+  // Outputs per wave (SW): more outputs per staged tile = less staging traffic, as long as about one
+  // workgroup per CU remains.  When the outputs alone cannot fill the chip and there are many tiles
+  // (big tables), keep SW = 4 and split the tiles over grid.z instead (partial slabs + a finish pass).
+  GatherPlan p{4, 1, nt > 0 ? nt : 1};
+  auto groups = [&](int sw) { return (long long)((n_out + kWaves * sw - 1) / (kWaves * sw)) * col_tiles; };
+  if (groups(4) < 192 && nt >= 8) {
+    int want = (int)((256 + groups(4) - 1) / groups(4));
+    if (want > nt / 2) want = nt / 2;
+    if (want > 16) want = 16;
+    p.tiles_per_split = (nt + want - 1) / want;
+    p.splits = (nt + p.tiles_per_split - 1) / p.tiles_per_split;
+    return p;
+  }
+  while (p.sw > 1 && groups(p.sw) < 448) p.sw >>= 1;  // ~2 workgroups per CU: one stages while the other gathers
+  return p;
 }
 
 template <int MODE>
-void launch_gather(int sg, dim3 block, hipStream_t s, const float* src, const float* bias, const u64* mask, int mw64,
-                   const float* sink, int n_out, int n_src, int sink_row, int L1, float* out, float* extra) {
-  const dim3 grid((n_out + 16 * sg - 1) / (16 * sg), L1 / kTC);
-  if (sg == 4)
-    hipLaunchKernelGGL((ftb_gather_kernel<4, MODE>), grid, block, 0, s, src, bias, mask, mw64, sink, n_out, n_src, sink_row, L1, out, extra);
-  else if (sg == 2)
-    hipLaunchKernelGGL((ftb_gather_kernel<2, MODE>), grid, block, 0, s, src, bias, mask, mw64, sink, n_out, n_src, sink_row, L1, out, extra);
-  else
-    hipLaunchKernelGGL((ftb_gather_kernel<1, MODE>), grid, block, 0, s, src, bias, mask, mw64, sink, n_out, n_src, sink_row, L1, out, extra);
+int launch_gather(hipStream_t s, const float* src, const float* bias, const unsigned char* tl, const unsigned char* tc, int nt,
+                  const float* sink, int n_out, int n_src, int sink_row, int L1, float* out, float* extra, void* scratch,
+                  int64_t scratch_bytes, const char* who) {
+  const int col_tiles = L1 / kTC;
+  const GatherPlan p = plan_gather(n_out, nt, col_tiles);
+  float* slabs = nullptr;
+  if (p.splits > 1) {
+    const int64_t need = (int64_t)p.splits * n_out * L1 * (int64_t)sizeof(float);
+    NNUE_REQUIRE(scratch && scratch_bytes >= need, NNUE_E_SCRATCH, "%s: scratch %lld < %lld bytes", who, (long long)scratch_bytes,
+                 (long long)need);
+    NNUE_REQUIRE(nnue_aligned16(scratch), NNUE_E_ARG, "%s: scratch must be 16-byte aligned", who);
+    slabs = static_cast<float*>(scratch);
+  }
+  const dim3 grid((n_out + kWaves * p.sw - 1) / (kWaves * p.sw), col_tiles, p.splits), block(512);
+#define NNUE_LAUNCH_GATHER(SWV)                                                                                          \
+  hipLaunchKernelGGL((ftb_gather_kernel<SWV, MODE>), grid, block, 0, s, src, bias, tl, tc, nt, sink, n_out, n_src, sink_row, L1, \
+                     p.tiles_per_split, out, extra, slabs)
+  if (p.sw == 4) NNUE_LAUNCH_GATHER(4);
+  else if (p.sw == 2) NNUE_LAUNCH_GATHER(2);
+  else NNUE_LAUNCH_GATHER(1);
+#undef NNUE_LAUNCH_GATHER
+  if (p.splits > 1) {
+    const long long q = (long long)n_out * (L1 / 4);
+    hipLaunchKernelGGL(ftb_finish_kernel<MODE>, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, s, slabs, p.splits, n_out, L1, src,
+                       bias, sink, sink_row, out, extra);
+  }
+  return nnue_launch_status(who);
 }
+
+int direct_rows(int F, int P) { return (F - 1 < P) ? F - 1 : P; }
 
 }  // namespace
 
 // =============================================================================== C ABI
 extern "C" int nnue_ftb_supported(int L1) { return (L1 == 256 || L1 == 512 || L1 == 1024) ? 1 : 0; }
 
+extern "C" int nnue_ftb_list_tiles(int B, int F, int P, int* tiles_fwd, int* tiles_bwd) {
+  if (B <= 0 || F <= 0 || P <= 0 || !tiles_fwd || !tiles_bwd) return NNUE_E_ARG;
+  const int d = direct_rows(F, P);
+  *tiles_fwd = d > 0 ? (d + kRT - 1) / kRT : 1;
+  *tiles_bwd = (B + kRT - 1) / kRT;
+  return NNUE_OK;
+}
+
+extern "C" int64_t nnue_ftb_scratch(int B, int F, int P, int L1) {
+  if (B <= 0 || F <= 0 || P <= 0 || L1 <= 0 || L1 % kTC) return 0;
+  int ntf = 0, ntb = 0;
+  nnue_ftb_list_tiles(B, F, P, &ntf, &ntb);
+  const GatherPlan a = plan_gather(B, ntf, L1 / kTC), b = plan_gather(F + 1, ntb, L1 / kTC);
+  const int64_t fa = a.splits > 1 ? (int64_t)a.splits * B * L1 : 0, fb = b.splits > 1 ? (int64_t)b.splits * (F + 1) * L1 : 0;
+  return ((fa > fb ? fa : fb) + 4) * (int64_t)sizeof(float);
+}
+
 extern "C" int nnue_binarize_bits(const float* conv_out, const float* thr, int B, int fps, int Gh, int Gw, int F,
                                   uint64_t* maskW, int pw64, uint64_t* maskT, int bw64, float* sink, int32_t* n,
-                                  nnue_stream_t stream) {
-  NNUE_REQUIRE(conv_out && thr && maskW && maskT && sink && n, NNUE_E_ARG, "nnue_binarize_bits: null pointer");
+                                  uint8_t* tlW, uint8_t* tcW, uint8_t* tlT, uint8_t* tcT, nnue_stream_t stream) {
+  NNUE_REQUIRE(conv_out && thr && maskW && maskT && sink && n && tlW && tcW && tlT && tcT, NNUE_E_ARG,
+               "nnue_binarize_bits: null pointer");
   NNUE_REQUIRE(B > 0 && fps > 0 && Gh > 0 && Gw > 0 && F > 0, NNUE_E_ARG,
                "nnue_binarize_bits: B=%d fps=%d Gh=%d Gw=%d F=%d must be positive", B, fps, Gh, Gw, F);
   const long long P64 = (long long)fps * Gh * Gw;
@@ -395,43 +518,48 @@ extern "C" int nnue_binarize_bits(const float* conv_out, const float* thr, int B
   const int P = (int)P64;
   NNUE_REQUIRE(pw64 % 2 == 0 && (long long)pw64 * 64 >= P, NNUE_E_SHAPE,
                "nnue_binarize_bits: pw64=%d must be even and cover %d positions", pw64, P);
-  NNUE_REQUIRE((long long)bw64 * 64 >= B && bw64 % 2 == 0, NNUE_E_SHAPE, "nnue_binarize_bits: bw64=%d must be even and cover %d samples", bw64, B);
+  NNUE_REQUIRE(bw64 % 2 == 0 && (long long)bw64 * 64 >= B, NNUE_E_SHAPE,
+               "nnue_binarize_bits: bw64=%d must be even and cover %d samples", bw64, B);
+  NNUE_REQUIRE(nnue_aligned16(tlW) && nnue_aligned16(tlT), NNUE_E_ARG, "nnue_binarize_bits: list buffers must be 16-byte aligned");
+  int ntf = 0, ntb = 0;
+  nnue_ftb_list_tiles(B, F, P, &ntf, &ntb);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(bits_rows_kernel, dim3(B), dim3(256), 0, s, conv_out, thr, Gh * Gw, P, F,
-                     reinterpret_cast<u64*>(maskW), pw64, sink, n);
-  hipLaunchKernelGGL(bits_transpose_kernel, dim3((F + 1 + 63) / 64, bw64), dim3(256), 0, s, conv_out, thr, sink, B, Gh * Gw,
-                     P, F, reinterpret_cast<u64*>(maskT), bw64);
+  hipLaunchKernelGGL(bits_rows_kernel, dim3(B), dim3(256), 0, s, conv_out, thr, Gh * Gw, P, F, reinterpret_cast<u64*>(maskW), pw64,
+                     sink, n, tlW, tcW, ntf);
+  hipLaunchKernelGGL(bits_transpose_kernel, dim3((F + 1 + kTrRows - 1) / kTrRows, ntb), dim3(256), 0, s, conv_out, thr, sink, B, Gh * Gw, P, F,
+                     reinterpret_cast<u64*>(maskT), bw64, tlT, tcT, ntb);
   return nnue_launch_status("nnue_binarize_bits");
 }
 
-extern "C" int nnue_ftb_forward(const float* weight, const float* bias, const uint64_t* maskW, int pw64, const float* sink,
-                                int B, int F, int P, int L1, float* out, nnue_stream_t stream) {
-  NNUE_REQUIRE(weight && bias && maskW && sink && out, NNUE_E_ARG, "nnue_ftb_forward: null pointer");
+extern "C" int nnue_ftb_forward(const float* weight, const float* bias, const uint8_t* tlW, const uint8_t* tcW, const float* sink,
+                                int B, int F, int P, int L1, float* out, void* scratch, int64_t scratch_bytes,
+                                nnue_stream_t stream) {
+  NNUE_REQUIRE(weight && bias && tlW && tcW && sink && out, NNUE_E_ARG, "nnue_ftb_forward: null pointer");
   NNUE_REQUIRE(B > 0 && F > 0 && P > 0, NNUE_E_ARG, "nnue_ftb_forward: B=%d F=%d P=%d must be positive", B, F, P);
   NNUE_REQUIRE(nnue_ftb_supported(L1), NNUE_E_SHAPE, "nnue_ftb_forward: L1=%d not supported (256/512/1024)", L1);
-  NNUE_REQUIRE(pw64 % 2 == 0 && (long long)pw64 * 64 >= P, NNUE_E_SHAPE, "nnue_ftb_forward: pw64=%d does not cover P=%d", pw64, P);
-  NNUE_REQUIRE(nnue_aligned16(weight) && nnue_aligned16(bias) && nnue_aligned16(out), NNUE_E_ARG,
+  NNUE_REQUIRE(nnue_aligned16(weight) && nnue_aligned16(bias) && nnue_aligned16(out) && nnue_aligned16(tlW), NNUE_E_ARG,
                "nnue_ftb_forward: pointers must be 16-byte aligned");
-  const bool has_sink = F - 1 < P;
-  const int direct = has_sink ? F - 1 : P;  // table rows selected by a position bit of their own
-  launch_gather<0>(pick_sg(B, L1 / kTC), dim3(256), static_cast<hipStream_t>(stream), weight, bias,
-                   reinterpret_cast<const u64*>(maskW), pw64, sink, B, direct, has_sink ? F - 1 : -1, L1, out, nullptr);
-  return nnue_launch_status("nnue_ftb_forward");
+  int ntf = 0, ntb = 0;
+  nnue_ftb_list_tiles(B, F, P, &ntf, &ntb);
+  const int d = direct_rows(F, P);
+  return launch_gather<0>(static_cast<hipStream_t>(stream), weight, bias, tlW, tcW, ntf, sink, B, d, (F - 1 < P) ? F - 1 : -1, L1,
+                          out, nullptr, scratch, scratch_bytes, "nnue_ftb_forward");
 }
 
-extern "C" int nnue_ftb_backward_weight(const float* d_out, const uint64_t* maskT, int bw64, const float* sink, int B, int F,
-                                        int L1, float* d_weight, float* d_bias, nnue_stream_t stream) {
-  NNUE_REQUIRE(d_out && maskT && sink, NNUE_E_ARG, "nnue_ftb_backward_weight: null pointer");
+extern "C" int nnue_ftb_backward_weight(const float* d_out, const uint8_t* tlT, const uint8_t* tcT, const float* sink, int B, int F,
+                                        int P, int L1, float* d_weight, float* d_bias, void* scratch, int64_t scratch_bytes,
+                                        nnue_stream_t stream) {
+  NNUE_REQUIRE(d_out && tlT && tcT && sink, NNUE_E_ARG, "nnue_ftb_backward_weight: null pointer");
   NNUE_REQUIRE(d_weight || d_bias, NNUE_E_ARG, "nnue_ftb_backward_weight: both outputs are null");
-  NNUE_REQUIRE(B > 0 && F > 0, NNUE_E_ARG, "nnue_ftb_backward_weight: B=%d F=%d must be positive", B, F);
+  NNUE_REQUIRE(B > 0 && F > 0 && P > 0, NNUE_E_ARG, "nnue_ftb_backward_weight: B=%d F=%d P=%d must be positive", B, F, P);
   NNUE_REQUIRE(nnue_ftb_supported(L1), NNUE_E_SHAPE, "nnue_ftb_backward_weight: L1=%d not supported (256/512/1024)", L1);
-  NNUE_REQUIRE(bw64 % 2 == 0 && (long long)bw64 * 64 >= B, NNUE_E_SHAPE, "nnue_ftb_backward_weight: bw64=%d does not cover B=%d", bw64, B);
-  NNUE_REQUIRE(nnue_aligned16(d_out) && nnue_aligned16(d_weight) && nnue_aligned16(d_bias), NNUE_E_ARG,
+  NNUE_REQUIRE(nnue_aligned16(d_out) && nnue_aligned16(d_weight) && nnue_aligned16(d_bias) && nnue_aligned16(tlT), NNUE_E_ARG,
                "nnue_ftb_backward_weight: pointers must be 16-byte aligned");
-  // outputs: F table rows + the bias row; row F-1 is valued by sink[], rows the map cannot reach have empty masks
-  launch_gather<1>(pick_sg(F + 1, L1 / kTC), dim3(256), static_cast<hipStream_t>(stream), d_out, nullptr,
-                   reinterpret_cast<const u64*>(maskT), bw64, sink, F + 1, B, F - 1, L1, d_weight, d_bias);
-  return nnue_launch_status("nnue_ftb_backward_weight");
+  int ntf = 0, ntb = 0;
+  nnue_ftb_list_tiles(B, F, P, &ntf, &ntb);
+  // outputs: F table rows + the bias row; row F-1 is valued by sink[]; rows the map cannot reach have empty lists
+  return launch_gather<1>(static_cast<hipStream_t>(stream), d_out, nullptr, tlT, tcT, ntb, sink, F + 1, B, F - 1, L1, d_weight, d_bias,
+                          scratch, scratch_bytes, "nnue_ftb_backward_weight");
 }
 
 extern "C" int nnue_ftb_backward_values(const float* d_out, const float* weight, const uint64_t* maskW, int pw64, int B,
@@ -442,10 +570,10 @@ extern "C" int nnue_ftb_backward_values(const float* d_out, const float* weight,
   NNUE_REQUIRE(pw64 % 2 == 0 && (long long)pw64 * 64 >= P, NNUE_E_SHAPE, "nnue_ftb_backward_values: pw64=%d does not cover P=%d", pw64, P);
   NNUE_REQUIRE(nnue_aligned16(d_out) && nnue_aligned16(weight), NNUE_E_ARG, "nnue_ftb_backward_values: pointers must be 16-byte aligned");
   const int r_last = (F - 1 < P) ? F - 1 : P - 1;
-  const int row_blocks = r_last / 32 + 1;
-  int spb = 64;  // samples per workgroup: fewer when the grid would be too small
-  while (spb > 16 && (long long)((B + spb - 1) / spb) * row_blocks < 256) spb >>= 1;
-  const dim3 grid((B + spb - 1) / spb, row_blocks), block(256);
+  const int row_blocks = r_last / 16 + 1;
+  int spb = 128;  // samples per workgroup: fewer when the grid would be too small
+  while (spb > 16 && (long long)((B + spb - 1) / spb) * row_blocks < 512) spb >>= 1;
+  const dim3 grid((B + spb - 1) / spb, row_blocks), block(512);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const u64* mw = reinterpret_cast<const u64*>(maskW);
   if (L1 == 1024)

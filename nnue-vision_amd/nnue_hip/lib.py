@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -37,10 +37,13 @@ SIGNATURES = {
     "nnue_ft_backward_values": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int,
                                          _c_p, _c_int, _c_p]),
     "nnue_ftb_supported": (_c_int, [_c_int]),
+    "nnue_ftb_list_tiles": (_c_int, [_c_int, _c_int, _c_int, _c_p, _c_p]),
+    "nnue_ftb_scratch": (_c_i64, [_c_int, _c_int, _c_int, _c_int]),
     "nnue_binarize_bits": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_int, _c_p, _c_int,
-                                    _c_p, _c_p, _c_p]),
-    "nnue_ftb_forward": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p]),
-    "nnue_ftb_backward_weight": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
+                                    _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
+    "nnue_ftb_forward": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_i64, _c_p]),
+    "nnue_ftb_backward_weight": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p,
+                                          _c_p, _c_i64, _c_p]),
     "nnue_ftb_backward_values": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p]),
     "nnue_classifier_scratch": (_c_i64, [_c_int, _c_int, _c_int, _c_int]),
     "nnue_classifier_forward": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_f,
@@ -316,11 +319,16 @@ def ft_backward_values(d_out: torch.Tensor, weight: torch.Tensor, act: ActList, 
 # ---------------------------------------------------------------------------- FeatureTransformer, binary features
 @dataclass
 class FeatureBits:
-    """Bit-mask form of the active features of one batch (layout: include/nnue_hip.h)."""
-    maskW: torch.Tensor  # int64 [B, pw64]     position bits per sample
-    maskT: torch.Tensor  # int64 [F+1, bw64]   sample bits per table row (+ bias row)
-    sink: torch.Tensor   # float32 [B]         active ids >= F-1
-    n: torch.Tensor      # int32 [B]           active positions
+    """Bit-mask + tile-list form of the active features of one batch (layout: include/nnue_hip.h)."""
+    maskW: torch.Tensor  # int64 [B, pw64]           position bits per sample
+    maskT: torch.Tensor  # int64 [F+1, bw64]         sample bits per table row (+ bias row)
+    sink: torch.Tensor   # float32 [B]               active ids >= F-1
+    n: torch.Tensor      # int32 [B]                 active positions
+    tlW: torch.Tensor    # uint8 [B, tiles_fwd, 128] rows to add per sample and table tile
+    tcW: torch.Tensor    # uint8 [B, tiles_fwd]
+    tlT: torch.Tensor    # uint8 [F+1, tiles_bwd, 128] samples to add per output row and batch tile
+    tcT: torch.Tensor    # uint8 [F+1, tiles_bwd]
+    scratch: torch.Tensor  # uint8, split-slab workspace of the gather kernels
     positions: int       # P = fps*Gh*Gw
     num_rows: int        # F
 
@@ -329,12 +337,20 @@ class FeatureBits:
         return self.n.shape[0]
 
     @staticmethod
-    def empty(batch: int, positions: int, num_rows: int, device) -> "FeatureBits":
+    def empty(batch: int, positions: int, num_rows: int, l1: int, device) -> "FeatureBits":
         pw64, bw64 = round_up(round_up(positions, 64) // 64, 2), round_up(round_up(batch, 64) // 64, 2)
+        tf, tb = ctypes.c_int(), ctypes.c_int()
+        if load().nnue_ftb_list_tiles(batch, num_rows, positions, ctypes.byref(tf), ctypes.byref(tb)) != 0:
+            raise ValueError("FeatureBits: sizes must be positive")
+        u8 = dict(dtype=torch.uint8, device=device)
         return FeatureBits(torch.empty((batch, pw64), dtype=torch.int64, device=device),
                            torch.empty((num_rows + 1, bw64), dtype=torch.int64, device=device),
                            torch.empty((batch,), dtype=torch.float32, device=device),
-                           torch.empty((batch,), dtype=torch.int32, device=device), positions, num_rows)
+                           torch.empty((batch,), dtype=torch.int32, device=device),
+                           torch.empty((batch, tf.value, 128), **u8), torch.empty((batch, tf.value), **u8),
+                           torch.empty((num_rows + 1, tb.value, 128), **u8), torch.empty((num_rows + 1, tb.value), **u8),
+                           torch.empty((max(16, int(load().nnue_ftb_scratch(batch, num_rows, positions, l1))),), **u8),
+                           positions, num_rows)
 
 
 def ftb_supported(l1: int) -> bool:
@@ -344,22 +360,16 @@ def ftb_supported(l1: int) -> bool:
 def use_bit_path(num_rows: int, l1: int) -> bool:
     """Which FeatureTransformer kernels the fused path uses for binary features.
 
-    "list" = id-list gather kernels (every sample gathers its rows from L2: fastest while the table is
-    L2-resident); "bits" = bit-mask kernels that stage table tiles in LDS once per sample tile (cut
-    memory-side traffic by the tile factor: for tables beyond the caches).  NNUE_FT_PATH=list|bits forces one;
-    default "auto" switches on the table size."""
+    "list" = id-list gather kernels (every sample gathers its rows from L2); "bits" = tile-list kernels that
+    stage table tiles in LDS once per sample tile (memory-side traffic drops by the tile factor).
+    NNUE_FT_PATH=list|bits forces one; the default takes the LDS-staged kernels whenever the width allows."""
     mode = os.environ.get("NNUE_FT_PATH", "auto")
     if mode == "list" or not ftb_supported(l1):
         return False
-    if mode == "bits":
-        return True
-    return num_rows * l1 * 4 > BITS_PATH_MIN_TABLE_BYTES
+    return True
 
 
-BITS_PATH_MIN_TABLE_BYTES = 32 << 20  # one XCD's L2 is 4 MiB; 32 MiB aggregate
-
-
-def binarize_bits(conv_out: torch.Tensor, thr: torch.Tensor, num_rows: int,
+def binarize_bits(conv_out: torch.Tensor, thr: torch.Tensor, num_rows: int, l1: int,
                   bits: Optional[FeatureBits] = None) -> FeatureBits:
     conv_out = _need(conv_out, torch.float32, "conv_out")
     if conv_out.dim() != 4:
@@ -367,12 +377,12 @@ def binarize_bits(conv_out: torch.Tensor, thr: torch.Tensor, num_rows: int,
     b, fps, gh, gw = conv_out.shape
     thr = _need(thr.reshape(-1), torch.float32, "threshold", (fps,))
     if bits is None:
-        bits = FeatureBits.empty(b, fps * gh * gw, num_rows, conv_out.device)
+        bits = FeatureBits.empty(b, fps * gh * gw, num_rows, l1, conv_out.device)
     elif bits.batch != b or bits.positions != fps * gh * gw or bits.num_rows != num_rows:
         raise ValueError("binarize_bits: bit buffers do not match the map")
     _call("nnue_binarize_bits", conv_out.data_ptr(), thr.data_ptr(), b, fps, gh, gw, num_rows, bits.maskW.data_ptr(),
           bits.maskW.shape[1], bits.maskT.data_ptr(), bits.maskT.shape[1], bits.sink.data_ptr(), bits.n.data_ptr(),
-          _stream(conv_out))
+          bits.tlW.data_ptr(), bits.tcW.data_ptr(), bits.tlT.data_ptr(), bits.tcT.data_ptr(), _stream(conv_out))
     return bits
 
 
@@ -384,8 +394,9 @@ def ftb_forward(weight: torch.Tensor, bias: torch.Tensor, bits: FeatureBits, out
         raise ValueError("ftb_forward: bits were built for a different table")
     if out is None:
         out = torch.empty((bits.batch, l1), dtype=torch.float32, device=weight.device)
-    _call("nnue_ftb_forward", weight.data_ptr(), bias.data_ptr(), bits.maskW.data_ptr(), bits.maskW.shape[1],
-          bits.sink.data_ptr(), bits.batch, f, bits.positions, l1, out.data_ptr(), _stream(weight))
+    _call("nnue_ftb_forward", weight.data_ptr(), bias.data_ptr(), bits.tlW.data_ptr(), bits.tcW.data_ptr(),
+          bits.sink.data_ptr(), bits.batch, f, bits.positions, l1, out.data_ptr(), bits.scratch.data_ptr(),
+          bits.scratch.numel(), _stream(weight))
     return out
 
 
@@ -399,8 +410,9 @@ def ftb_backward_weight(d_out: torch.Tensor, bits: FeatureBits, d_weight: Option
         d_weight = torch.empty((bits.num_rows, l1), dtype=torch.float32, device=d_out.device)
     if want_bias and d_bias is None:
         d_bias = torch.empty((l1,), dtype=torch.float32, device=d_out.device)
-    _call("nnue_ftb_backward_weight", d_out.data_ptr(), bits.maskT.data_ptr(), bits.maskT.shape[1], bits.sink.data_ptr(),
-          b, bits.num_rows, l1, _ptr(d_weight if want_weight else None), _ptr(d_bias if want_bias else None), _stream(d_out))
+    _call("nnue_ftb_backward_weight", d_out.data_ptr(), bits.tlT.data_ptr(), bits.tcT.data_ptr(), bits.sink.data_ptr(),
+          b, bits.num_rows, bits.positions, l1, _ptr(d_weight if want_weight else None),
+          _ptr(d_bias if want_bias else None), bits.scratch.data_ptr(), bits.scratch.numel(), _stream(d_out))
     return d_weight, d_bias
 
 

@@ -65,7 +65,7 @@ class NnueFn(torch.autograd.Function):
         # binary features: bit masks + LDS-staged tiles when the width allows, id lists otherwise
         ctx.use_bits = lib.use_bit_path(ft_w.shape[0], ft_w.shape[1])
         if ctx.use_bits:
-            feats = lib.binarize_bits(conv_out, thr, ft_w.shape[0])
+            feats = lib.binarize_bits(conv_out, thr, ft_w.shape[0], ft_w.shape[1])
             ft = lib.ftb_forward(ft_w, ft_b, feats)
         else:
             feats = lib.binarize_features(conv_out, thr, ft_w.shape[0])

@@ -146,7 +146,7 @@ class NnueTrainer:
         self.conv_out = torch.empty((B, self.fps, self.gh, self.gw), **f32)
         # binary features: bit masks + LDS-staged FT kernels when the width allows, id lists otherwise
         self.use_bits = lib.use_bit_path(self.F, self.L1)
-        self.bits = lib.FeatureBits.empty(B, self.P, self.F, self.dev) if self.use_bits else None
+        self.bits = lib.FeatureBits.empty(B, self.P, self.F, self.L1, self.dev) if self.use_bits else None
         self.act = None if self.use_bits else lib.ActList.empty(B, self.P, self.F, self.dev)
         self.ft = torch.empty((B, self.L1), **f32)
         self.h1 = torch.empty((B, self.L2), **f32)
@@ -177,7 +177,7 @@ class NnueTrainer:
         p = self.p
         lib.conv3x3_forward(self.images, p["conv.weight"], self.stride, out=self.conv_out)
         if self.use_bits:
-            lib.binarize_bits(self.conv_out, p["visual_threshold"], self.F, bits=self.bits)
+            lib.binarize_bits(self.conv_out, p["visual_threshold"], self.F, self.L1, bits=self.bits)
             lib.ftb_forward(p["input.weight"], p["input.bias"], self.bits, out=self.ft)
         else:
             lib.binarize_features(self.conv_out, p["visual_threshold"], self.F, act=self.act)

@@ -48,7 +48,7 @@ def test_bits_and_products(hip, geom, thr_scale):
     p = fps * gh * gw
     xd, td, wd, bd, ud = (t.to(DEV) for t in (x, thr, w, bias, up))
 
-    bits = hip.binarize_bits(xd, td, f)
+    bits = hip.binarize_bits(xd, td, f, l1)
     on = (x > thr.view(1, -1, 1, 1)).reshape(b, p)
     assert torch.equal(unpack(bits.maskW, p), on)                       # bit-exact ids
     assert not bool(unpack(bits.maskW, bits.maskW.shape[1] * 64)[:, p:].any())  # padding bits are zero
@@ -61,6 +61,27 @@ def test_bits_and_products(hip, geom, thr_scale):
     assert not bool(mt[direct:f - 1].any())
     assert torch.equal(mt[f - 1], sink != 0) and bool(mt[f].all())
     assert not bool(unpack(bits.maskT, bits.maskT.shape[1] * 64)[:, b:].any())
+
+    # tile lists decode to exactly the mask bits, ascending, padded with 128
+    def decode(tl, tc):
+        tl, tc = tl.cpu().long(), tc.cpu().long()
+        e = torch.arange(128)
+        pos = ((e >> 2) & 3) * 32 + (e >> 4) * 4 + (e & 3)
+        return tl[..., pos], tc  # entry order
+    lw, cw = decode(bits.tlW, bits.tcW)
+    for t in range(lw.shape[1]):
+        seg = on[:, t * 128:(t + 1) * 128].clone()
+        seg[:, max(0, direct - t * 128):] = False
+        assert torch.equal(cw[:, t], seg.sum(1)), t
+        for s in range(0, b, max(1, b // 7)):
+            k = int(cw[s, t])
+            assert lw[s, t, :k].tolist() == seg[s].nonzero().flatten().tolist()
+            assert bool((lw[s, t, k:] == 128).all())
+    lt, ct = decode(bits.tlT, bits.tcT)
+    assert torch.equal(ct.sum(1), mt.sum(1))
+    for r in (0, direct // 2, f - 1, f):
+        got = [int(v) + 128 * t for t in range(lt.shape[1]) for v in lt[r, t, :int(ct[r, t])]]
+        assert got == mt[r].nonzero().flatten().tolist(), r
 
     # oracle (float64) through the id-list form
     idx, _ = orc.active_lists(x, thr)
@@ -80,10 +101,12 @@ def test_bits_and_products(hip, geom, thr_scale):
     assert_close_grad(d_x, ref_dx, "ftb d_conv_out")
     assert bool((d_x.cpu()[~on] == 0).all())  # inactive positions are exactly zero (written, not left over)
 
-    # the list kernels on the same batch: weight gradient sums the same rows in the same order
+    # the list kernels on the same batch (different fp32 summation order: the LDS kernels keep four partial sums)
     act = hip.binarize_features(xd, td, f)
     l_w, l_b = hip.ft_backward_weight(ud, act, f)
-    assert torch.equal(d_w, l_w) and torch.equal(d_b, l_b)
+    assert_close_grad(d_w, l_w, "ftb vs list d_weight")
+    assert_close_grad(d_b, l_b, "ftb vs list d_bias")
+    assert torch.equal(d_w, hip.ftb_backward_weight(ud, bits)[0])  # and is itself bitwise reproducible
     assert_close_logits(out, hip.ft_forward(wd, bd, act), "ftb vs list forward")
     assert_close_grad(d_x, hip.ft_backward_values(ud, wd, act, p), "ftb vs list values")
     # bitwise reproducible
@@ -92,6 +115,6 @@ def test_bits_and_products(hip, geom, thr_scale):
 
 def test_ftb_rejects_unsupported_width(hip):
     assert hip.ftb_supported(1024) and hip.ftb_supported(256) and not hip.ftb_supported(64) and not hip.ftb_supported(2048)
-    bits = hip.FeatureBits.empty(4, 32, 16, DEV)
+    bits = hip.FeatureBits.empty(4, 32, 16, 64, DEV)
     with pytest.raises(hip.NnueHipError, match="not supported"):
         hip.ftb_forward(torch.zeros(16, 64, device=DEV), torch.zeros(64, device=DEV), bits)
