@@ -146,7 +146,7 @@ def main():
     # ---- instrumented pass: per-entry-point durations from HIP events on the launch stream
     ftp = "nnue_ftb" if trainer.use_bits else "nnue_ft"  # bit-mask/LDS-staged kernels or id-list kernels
     names = ["nnue_conv3x3_forward", "nnue_binarize_bits" if trainer.use_bits else "nnue_binarize_features",
-             f"{ftp}_forward", "nnue_classifier_forward", "nnue_cross_entropy", "nnue_classifier_backward",
+             f"{ftp}_forward", "nnue_classifier_train_step",
              f"{ftp}_backward_weight", f"{ftp}_backward_values", "nnue_ste_conv_backward", "nnue_sgd_step"]
     timers = {k: [] for k in names}
     isteps = max(5, min(50, args.steps))

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 3
+#define NNUE_HIP_ABI_VERSION 4
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -191,6 +191,22 @@ int nnue_classifier_backward(const float* x, int pairwise,
                              float* d_x, float* d_w1, float* d_b1, float* d_w2, float* d_b2,
                              float* d_w3, float* d_b3,
                              void* scratch, int64_t scratch_bytes, nnue_stream_t stream);
+
+/* The three calls above as ONE training step of the pairwise/classifier block with mean cross-entropy
+ * (nnue.py:660-669, :728-734 + compute_loss, train.py:250-254, and their autograd): same results as
+ * nnue_classifier_forward -> nnue_cross_entropy(grad_scale) -> nnue_classifier_backward, but the narrow
+ * layers, the loss and their backward run per sample in a single kernel.  d_x may be NULL.
+ * scratch >= nnue_classifier_train_scratch(B, L1, L2, L3, C) bytes. */
+int64_t nnue_classifier_train_scratch(int B, int L1, int L2, int L3, int C);
+int nnue_classifier_train_step(const float* x, int pairwise,
+                               const float* w1, const float* b1, const float* w2, const float* b2,
+                               const float* w3, const float* b3, float clip,
+                               const int64_t* labels, float grad_scale,
+                               int B, int L1, int L2, int L3, int C,
+                               float* h1, float* h2, float* logits, float* sample_loss, float* loss,
+                               float* d_x, float* d_w1, float* d_b1, float* d_w2, float* d_b2,
+                               float* d_w3, float* d_b3,
+                               void* scratch, int64_t scratch_bytes, nnue_stream_t stream);
 
 /* ---- loss + step tail ---------------------------------------------------------- */
 

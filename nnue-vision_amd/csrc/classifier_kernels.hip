@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void l1_backward_w_mfma(const float* __restric
       bv[t] = v;
     }
   };
-  constexpr int kSteps = 4;  // K steps (of 4 samples) whose loads are issued together
+  constexpr int kSteps = 8;  // K steps (of 4 samples) whose loads are issued together
   for (int b0 = b_lo; b0 < b_hi; b0 += 4 * kSteps) {
     float a[kSteps][kBwTileM], bv[kSteps][kBwTileN];
 #pragma unroll
@@ -297,36 +297,35 @@ __global__ __launch_bounds__(256) void l1_backward_x_mfma(const float* __restric
   const bool row_ok = row < B;
   const float* __restrict__ dz = d_z1 + (size_t)(row_ok ? row : 0) * L2;
   f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-  auto load_ops = [&](int kb, float4& a, float (&b0v)[4], float (&b1v)[4]) {
-    const int k = kb + 4 * q;
-    a = row_ok ? *reinterpret_cast<const float4*>(dz + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* __restrict__ wk = w1 + (size_t)k * L1 + r;
+  // K is walked in chunks of up to 4 blocks of 16; every load of a chunk is issued before its MFMAs, so a
+  // wave pays one L2 round trip per chunk (L2 = 128: two) instead of one per block
+  constexpr int KC = 4;
+  for (int kb0 = 0; kb0 < L2; kb0 += 16 * KC) {  // L2 % 16 == 0
+    float4 a[KC];
+    float b0v[KC][4], b1v[KC][4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      b0v[e] = wk[(size_t)e * L1 + c0];
-      b1v[e] = wk[(size_t)e * L1 + c1];
+    for (int u = 0; u < KC; ++u) {
+      const int kb = kb0 + 16 * u;
+      const bool in = kb < L2;  // wave-uniform
+      const int k = (in ? kb : 0) + 4 * q;
+      a[u] = (row_ok && in) ? *reinterpret_cast<const float4*>(dz + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* __restrict__ wk = w1 + (size_t)k * L1 + r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        b0v[u][e] = in ? wk[(size_t)e * L1 + c0] : 0.f;
+        b1v[u][e] = in ? wk[(size_t)e * L1 + c1] : 0.f;
+      }
     }
-  };
-  float4 a;
-  float b0v[4], b1v[4];
-  load_ops(0, a, b0v, b1v);
-  for (int kb = 0; kb < L2; kb += 16) {  // L2 % 16 == 0
-    float4 an;
-    float n0[4], n1[4];
-    load_ops(kb + 16 < L2 ? kb + 16 : kb, an, n0, n1);  // prefetch the next K block
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0v[0], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1v[0], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0v[1], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1v[1], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0v[2], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1v[2], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0v[3], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1v[3], acc1, 0, 0, 0);
-    a = an;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      b0v[e] = n0[e];
-      b1v[e] = n1[e];
+    for (int u = 0; u < KC; ++u) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b0v[u][0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b1v[u][0], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b0v[u][1], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b1v[u][1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b0v[u][2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b1v[u][2], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b0v[u][3], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b1v[u][3], acc1, 0, 0, 0);
     }
   }
 #pragma unroll
@@ -407,8 +406,10 @@ __global__ __launch_bounds__(128) void tail_backward_kernel(const float* __restr
   }
 }
 
-// Small batch reductions, one wave per output element, lanes stride over the batch:
-//   d_w3 [C, L3] | d_b3 [C] | d_w2 [L3, L2] | d_b2 [L3] | d_b1 [L2]
+// Small batch reductions; lanes stride over the batch, one wave per group of outputs:
+//   d_w3 [C, L3] | d_w2 [L3, L2]   four adjacent columns per wave (one float4 load feeds four sums; needs
+//                                   L3 % 4 == 0 resp. L2 % 4 == 0, else one column per wave)
+//   d_b3 [C] | d_b2 [L3] | d_b1 [L2]  one output per wave
 __global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restrict__ d_logits,
                                                           const float* __restrict__ d_z2, const float* __restrict__ d_z1,
                                                           const float* __restrict__ h1, const float* __restrict__ h2,
@@ -417,22 +418,37 @@ __global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restric
                                                           float* __restrict__ d_b2, float* __restrict__ d_b1) {
   long long o = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const long long n_w3 = (long long)C * L3, n_w2 = (long long)L3 * L2;
+  const int v3 = (L3 % 4 == 0) ? 4 : 1, v2 = (L2 % 4 == 0) ? 4 : 1;
+  const long long n_w3 = (long long)C * (L3 / v3), n_w2 = (long long)L3 * (L2 / v2);
   const float* pa;
   const float* pb = nullptr;
-  int sa, sb = 0;
+  int sa, sb = 0, vec = 1;
   float* dst;
   if (o < n_w3) {
-    pa = d_logits + o / L3; sa = C; pb = h2 + o % L3; sb = L3; dst = d_w3 + o;
-  } else if ((o -= n_w3) < C) {
+    const int c = (int)(o / (L3 / v3)), j = (int)(o % (L3 / v3)) * v3;
+    pa = d_logits + c; sa = C; pb = h2 + j; sb = L3; dst = d_w3 + (size_t)c * L3 + j; vec = v3;
+  } else if ((o -= n_w3) < n_w2) {
+    const int j = (int)(o / (L2 / v2)), k = (int)(o % (L2 / v2)) * v2;
+    pa = d_z2 + j; sa = L3; pb = h1 + k; sb = L2; dst = d_w2 + (size_t)j * L2 + k; vec = v2;
+  } else if ((o -= n_w2) < C) {
     pa = d_logits + o; sa = C; dst = d_b3 + o;
-  } else if ((o -= C) < n_w2) {
-    pa = d_z2 + o / L2; sa = L3; pb = h1 + o % L2; sb = L2; dst = d_w2 + o;
-  } else if ((o -= n_w2) < L3) {
+  } else if ((o -= C) < L3) {
     pa = d_z2 + o; sa = L3; dst = d_b2 + o;
   } else if ((o -= L3) < L2) {
     pa = d_z1 + o; sa = L2; dst = d_b1 + o;
   } else {
+    return;
+  }
+  if (vec == 4) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int b = lane; b < B; b += 64) {
+      const float a = pa[(size_t)b * sa];
+      const float4 v = *reinterpret_cast<const float4*>(pb + (size_t)b * sb);
+      acc.x = fmaf(a, v.x, acc.x); acc.y = fmaf(a, v.y, acc.y); acc.z = fmaf(a, v.z, acc.z); acc.w = fmaf(a, v.w, acc.w);
+    }
+    acc.x = wave_sum(acc.x); acc.y = wave_sum(acc.y); acc.z = wave_sum(acc.z); acc.w = wave_sum(acc.w);
+    if (lane == 0) { dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z; dst[3] = acc.w; }
     return;
   }
   float acc = 0.f;
@@ -445,6 +461,124 @@ __global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restric
   }
   acc = wave_sum(acc);
   if (lane == 0) *dst = acc;
+}
+
+// ------------------------------------------------------------------ fused narrow layers + loss (training)
+// Per sample, out of LDS: h1 = act(sum of split-K slabs + b1), h2, logits, softmax cross-entropy, d_logits,
+// then back through the two narrow layers to d_z2 and d_z1.  Replaces tail_forward + cross_entropy +
+// tail_backward (three launches and two round trips of logits / d_logits through memory).
+// Dot products use 4 threads per output (coalesced 16-byte runs of each weight row).
+__device__ __forceinline__ float block_reduce_128(float v, bool is_max, float* red) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    const float o = __shfl_xor(v, s);
+    v = is_max ? fmaxf(v, o) : v + o;
+  }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float r = is_max ? fmaxf(red[0], red[1]) : red[0] + red[1];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(128) void tail_train_kernel(const float* __restrict__ part, int ksplit,
+                                                         const float* __restrict__ b1, const float* __restrict__ w2,
+                                                         const float* __restrict__ b2, const float* __restrict__ w3,
+                                                         const float* __restrict__ b3, float clip,
+                                                         const int64_t* __restrict__ labels, float scale_over_b, int B,
+                                                         int L2, int L3, int C, float* __restrict__ h1,
+                                                         float* __restrict__ h2, float* __restrict__ logits,
+                                                         float* __restrict__ sample_loss, float* __restrict__ d_logits,
+                                                         float* __restrict__ d_z1, float* __restrict__ d_z2) {
+  extern __shared__ float lds[];  // h1 [L2] | h2 [L3] | logits / d_logits [C] | d_z2 [L3] | red [2]
+  float* h1s = lds;
+  float* h2s = h1s + L2;
+  float* lgs = h2s + L3;
+  float* dz2s = lgs + C;
+  float* red = dz2s + L3;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int og = tid >> 2, part4 = tid & 3;
+  for (int j = tid; j < L2; j += 128) {
+    float z = b1[j];
+    for (int s = 0; s < ksplit; ++s) z += part[((size_t)s * B + b) * L2 + j];
+    const float h = act_fn(z, clip);
+    h1s[j] = h;
+    h1[(size_t)b * L2 + j] = h;
+  }
+  __syncthreads();
+  for (int j0 = 0; j0 < L3; j0 += 32) {
+    const int j = j0 + og;
+    float z = 0.f;
+    if (j < L3) {
+      const float* __restrict__ wr = w2 + (size_t)j * L2;
+      for (int k = part4; k < L2; k += 4) z = fmaf(wr[k], h1s[k], z);
+    }
+    z += __shfl_xor(z, 1);
+    z += __shfl_xor(z, 2);
+    if (j < L3 && part4 == 0) {
+      const float h = act_fn(z + b2[j], clip);
+      h2s[j] = h;
+      h2[(size_t)b * L3 + j] = h;
+    }
+  }
+  __syncthreads();
+  for (int c0 = 0; c0 < C; c0 += 32) {
+    const int c = c0 + og;
+    float z = 0.f;
+    if (c < C) {
+      const float* __restrict__ wr = w3 + (size_t)c * L3;
+      for (int k = part4; k < L3; k += 4) z = fmaf(wr[k], h2s[k], z);
+    }
+    z += __shfl_xor(z, 1);
+    z += __shfl_xor(z, 2);
+    if (c < C && part4 == 0) {
+      z += b3[c];
+      lgs[c] = z;
+      logits[(size_t)b * C + c] = z;
+    }
+  }
+  __syncthreads();
+  // softmax cross-entropy of this sample and its gradient
+  float mx = -INFINITY;
+  for (int c = tid; c < C; c += 128) mx = fmaxf(mx, lgs[c]);
+  mx = block_reduce_128(mx, true, red);
+  float se = 0.f;
+  for (int c = tid; c < C; c += 128) se += expf(lgs[c] - mx);
+  se = block_reduce_128(se, false, red);
+  const int64_t y = labels[b];
+  const bool ok = y >= 0 && y < C;
+  if (tid == 0) sample_loss[b] = ok ? (mx + logf(se)) - lgs[y] : 0.0f;
+  const float inv = 1.0f / se;
+  __syncthreads();  // every thread has read lgs[y] / the logits it needs before they are overwritten
+  for (int c = tid; c < C; c += 128) {
+    const float g = ok ? (expf(lgs[c] - mx) * inv - (c == y ? 1.0f : 0.0f)) * scale_over_b : 0.0f;
+    lgs[c] = g;
+    d_logits[(size_t)b * C + c] = g;
+  }
+  __syncthreads();
+  for (int j = tid; j < L3; j += 128) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s = fmaf(lgs[c], w3[(size_t)c * L3 + j], s);
+    const float v = s * gate_fn(h2s[j], clip);
+    dz2s[j] = v;
+    d_z2[(size_t)b * L3 + j] = v;
+  }
+  __syncthreads();
+  for (int k = tid; k < L2; k += 128) {
+    float s = 0.f;
+    for (int j = 0; j < L3; ++j) s = fmaf(dz2s[j], w2[(size_t)j * L2 + k], s);
+    d_z1[(size_t)b * L2 + k] = s * gate_fn(h1s[k], clip);
+  }
+}
+
+__global__ __launch_bounds__(256) void loss_mean_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += v[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
 }
 
 // ------------------------------------------------------------------ shape policy (shared by scratch + launch)
@@ -549,7 +683,7 @@ extern "C" int nnue_classifier_backward(const float* x, int pairwise, const floa
   hipLaunchKernelGGL(tail_backward_kernel, dim3(B), dim3(128), (size_t)(C + L3) * sizeof(float), s, d_logits, h1, h2, w2, w3,
                      clip, L2, L3, C, d_z1, d_z2);
   {
-    const long long outs = (long long)C * L3 + C + (long long)L3 * L2 + L3 + L2;
+    const long long outs = (long long)C * (L3 % 4 == 0 ? L3 / 4 : L3) + (long long)L3 * (L2 % 4 == 0 ? L2 / 4 : L2) + C + L3 + L2;
     hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, s, d_logits, d_z2, d_z1, h1, h2, B,
                        L2, L3, C, d_w3, d_b3, d_w2, d_b2, d_b1);
   }
@@ -578,4 +712,93 @@ extern "C" int nnue_classifier_backward(const float* x, int pairwise, const floa
     }
   }
   return nnue_launch_status("nnue_classifier_backward");
+}
+
+// ---------------------------------------------------------------- fused training step of the classifier block
+namespace {
+struct TrainLayout {
+  int64_t part, d_z1, d_z2, d_logits, slabs, total;  // float offsets
+};
+TrainLayout train_layout(const ClsPlan& p, int B, int L1, int L2, int L3, int C) {
+  TrainLayout t{};
+  int64_t off = 0;
+  auto take = [&](int64_t n) { const int64_t o = off; off += nnue_round_up(n, 4); return o; };
+  t.part = take((int64_t)p.fwd_ksplit * B * L2);
+  t.d_z1 = take((int64_t)B * L2);
+  t.d_z2 = take((int64_t)B * L3);
+  t.d_logits = take((int64_t)B * C);
+  t.slabs = take(p.bww_ksplit > 1 ? (int64_t)p.bww_ksplit * L2 * L1 : 0);
+  t.total = off + 4;
+  return t;
+}
+}  // namespace
+
+extern "C" int64_t nnue_classifier_train_scratch(int B, int L1, int L2, int L3, int C) {
+  if (B <= 0 || L1 <= 0 || L2 <= 0 || L3 <= 0 || C <= 0) return 0;
+  const int64_t a = train_layout(make_plan(B, L1, L2, 0), B, L1, L2, L3, C).total;
+  const int64_t b = train_layout(make_plan(B, L1, L2, 1), B, L1, L2, L3, C).total;
+  return (a > b ? a : b) * (int64_t)sizeof(float);
+}
+
+extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const float* w1, const float* b1, const float* w2,
+                                          const float* b2, const float* w3, const float* b3, float clip,
+                                          const int64_t* labels, float grad_scale, int B, int L1, int L2, int L3, int C,
+                                          float* h1, float* h2, float* logits, float* sample_loss, float* loss, float* d_x,
+                                          float* d_w1, float* d_b1, float* d_w2, float* d_b2, float* d_w3, float* d_b3,
+                                          void* scratch, int64_t scratch_bytes, nnue_stream_t stream) {
+  NNUE_REQUIRE(x && w1 && b1 && w2 && b2 && w3 && b3 && labels && h1 && h2 && logits && sample_loss && loss && scratch,
+               NNUE_E_ARG, "nnue_classifier_train_step: null pointer");
+  NNUE_REQUIRE(d_w1 && d_b1 && d_w2 && d_b2 && d_w3 && d_b3, NNUE_E_ARG, "nnue_classifier_train_step: null gradient pointer");
+  NNUE_REQUIRE(B > 0 && L1 > 0 && L2 > 0 && L3 > 0 && C > 0, NNUE_E_ARG,
+               "nnue_classifier_train_step: B=%d L1=%d L2=%d L3=%d C=%d must be positive", B, L1, L2, L3, C);
+  NNUE_REQUIRE(!pairwise || L1 % 2 == 0, NNUE_E_SHAPE, "nnue_classifier_train_step: pairwise needs an even L1 (got %d)", L1);
+  const int64_t tail_lds = ((int64_t)L2 + 2 * L3 + C + 2) * 4;
+  NNUE_REQUIRE(tail_lds <= 64 * 1024, NNUE_E_SHAPE, "nnue_classifier_train_step: L2+2*L3+C too large for the LDS tail");
+  const ClsPlan p = make_plan(B, L1, L2, pairwise);
+  const TrainLayout t = train_layout(p, B, L1, L2, L3, C);
+  NNUE_REQUIRE(scratch_bytes >= t.total * (int64_t)sizeof(float), NNUE_E_SCRATCH,
+               "nnue_classifier_train_step: scratch %lld < %lld bytes", (long long)scratch_bytes, (long long)(t.total * 4));
+  NNUE_REQUIRE(nnue_aligned16(x) && nnue_aligned16(w1) && nnue_aligned16(scratch) && nnue_aligned16(d_w1) && nnue_aligned16(h1) &&
+                   nnue_aligned16(h2),
+               NNUE_E_ARG, "nnue_classifier_train_step: pointers must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* base = static_cast<float*>(scratch);
+  float *part = base + t.part, *d_z1 = base + t.d_z1, *d_z2 = base + t.d_z2, *d_logits = base + t.d_logits, *slabs = base + t.slabs;
+  if (p.fwd_mfma) {
+    const long long waves = (long long)((B + 15) / 16) * ((L2 + 63) / 64) * p.fwd_ksplit;
+    hipLaunchKernelGGL(l1_forward_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, B, L1, L2, p.fwd_ksplit, part);
+  } else {
+    const long long waves = (long long)B * L2;
+    hipLaunchKernelGGL(l1_forward_simple, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, B, L1, L2, part);
+  }
+  hipLaunchKernelGGL(tail_train_kernel, dim3(B), dim3(128), (size_t)tail_lds, s, part, p.fwd_ksplit, b1, w2, b2, w3, b3, clip, labels,
+                     grad_scale / (float)B, B, L2, L3, C, h1, h2, logits, sample_loss, d_logits, d_z1, d_z2);
+  hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(256), 0, s, sample_loss, B, loss);
+  {
+    const long long outs = (long long)C * (L3 % 4 == 0 ? L3 / 4 : L3) + (long long)L3 * (L2 % 4 == 0 ? L2 / 4 : L2) + C + L3 + L2;
+    hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, s, d_logits, d_z2, d_z1, h1, h2, B, L2, L3, C,
+                       d_w3, d_b3, d_w2, d_b2, d_b1);
+  }
+  if (p.bww_mfma) {
+    const long long waves = (long long)(L2 / 32) * (L1 / 64) * p.bww_ksplit;
+    float* target = p.bww_ksplit > 1 ? slabs : d_w1;
+    hipLaunchKernelGGL(l1_backward_w_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, d_z1, B, L1, L2, p.bww_ksplit,
+                       p.bww_klen, target);
+    if (p.bww_ksplit > 1) {
+      const long long count = (long long)L2 * L1;
+      hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, s, slabs, p.bww_ksplit, count, d_w1);
+    }
+  } else {
+    hipLaunchKernelGGL(l1_backward_w_simple, dim3(L2, (L1 + 255) / 256), dim3(256), 0, s, x, pairwise, d_z1, B, L1, L2, d_w1);
+  }
+  if (d_x) {
+    if (p.bwx_mfma) {
+      const long long waves = (long long)((B + 15) / 16) * (L1 / 32);
+      hipLaunchKernelGGL(l1_backward_x_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1, L2, d_x);
+    } else {
+      const int cols = pairwise ? L1 / 2 : L1;
+      hipLaunchKernelGGL(l1_backward_x_simple, dim3(B, (cols + 255) / 256), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1, L2, d_x);
+    }
+  }
+  return nnue_launch_status("nnue_classifier_train_step");
 }

@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -52,6 +52,11 @@ SIGNATURES = {
     "nnue_classifier_backward": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p, _c_f, _c_p, _c_p, _c_p,
                                           _c_int, _c_int, _c_int, _c_int, _c_int,
                                           _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
+    "nnue_classifier_train_scratch": (_c_i64, [_c_int, _c_int, _c_int, _c_int, _c_int]),
+    "nnue_classifier_train_step": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_f, _c_p, _c_f,
+                                            _c_int, _c_int, _c_int, _c_int, _c_int,
+                                            _c_p, _c_p, _c_p, _c_p, _c_p,
+                                            _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
     "nnue_cross_entropy": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_f, _c_p, _c_p, _c_p, _c_p]),
     "nnue_sgd_scratch": (_c_i64, [_c_i64]),
     "nnue_sgd_step": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_int,
@@ -489,6 +494,42 @@ def classifier_backward(x, pairwise: bool, w1, w2, w3, h1, h2, d_logits, clip: f
           _ptr(d_x if want_dx else None), *[g.data_ptr() for g in grads], scratch.data_ptr(), scratch.numel(),
           _stream(x))
     return (d_x if want_dx else None), grads
+
+
+def classifier_train_scratch_bytes(b: int, l1: int, l2: int, l3: int, c: int) -> int:
+    return int(load().nnue_classifier_train_scratch(b, l1, l2, l3, c))
+
+
+def classifier_train_step(x, pairwise: bool, w1, b1, w2, b2, w3, b3, labels, grad_scale: float = 1.0, clip: float = 0.0,
+                          want_dx: bool = True, scratch: Optional[torch.Tensor] = None, out=None, loss_out=None,
+                          grads=None, d_x=None):
+    """Forward + mean cross-entropy + backward of the classifier block in one C call.
+    Returns (h1, h2, logits), (sample_loss, loss), d_x, grads."""
+    x = _need(x, torch.float32, "classifier input")
+    b, l1 = x.shape
+    l2, l3, c = w1.shape[0], w2.shape[0], w3.shape[0]
+    w1 = _need(w1, torch.float32, "classifier.0.weight", (l2, l1))
+    b1 = _need(b1, torch.float32, "classifier.0.bias", (l2,))
+    w2 = _need(w2, torch.float32, "classifier.2.weight", (l3, l2))
+    b2 = _need(b2, torch.float32, "classifier.2.bias", (l3,))
+    w3 = _need(w3, torch.float32, "classifier.4.weight", (c, l3))
+    b3 = _need(b3, torch.float32, "classifier.4.bias", (c,))
+    labels = _need(labels, torch.int64, "labels", (b,))
+    dev = x.device
+    mk = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+    if scratch is None:
+        scratch = torch.empty((classifier_train_scratch_bytes(b, l1, l2, l3, c),), dtype=torch.uint8, device=dev)
+    h1, h2, logits = out if out is not None else (mk(b, l2), mk(b, l3), mk(b, c))
+    sample_loss, loss = loss_out if loss_out is not None else (mk(b), mk())
+    if grads is None:
+        grads = (mk(l2, l1), mk(l2), mk(l3, l2), mk(l3), mk(c, l3), mk(c))
+    if want_dx and d_x is None:
+        d_x = mk(b, l1)
+    _call("nnue_classifier_train_step", x.data_ptr(), int(bool(pairwise)), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+          b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), float(clip), labels.data_ptr(), float(grad_scale), b, l1, l2, l3, c,
+          h1.data_ptr(), h2.data_ptr(), logits.data_ptr(), sample_loss.data_ptr(), loss.data_ptr(),
+          _ptr(d_x if want_dx else None), *[g.data_ptr() for g in grads], scratch.data_ptr(), scratch.numel(), _stream(x))
+    return (h1, h2, logits), (sample_loss, loss), (d_x if want_dx else None), grads
 
 
 # ---------------------------------------------------------------------------- loss + step tail

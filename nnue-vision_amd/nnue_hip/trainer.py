@@ -159,7 +159,8 @@ class NnueTrainer:
         self.d_conv_out = torch.empty((B, self.P), **f32)
         self.grad_norm = torch.zeros((), **f32)
         u8 = dict(dtype=torch.uint8, device=self.dev)
-        self.cls_scratch = torch.empty((lib.classifier_scratch_bytes(B, self.L1, self.L2, self.L3),), **u8)
+        self.cls_scratch = torch.empty((max(lib.classifier_scratch_bytes(B, self.L1, self.L2, self.L3),
+                                            lib.classifier_train_scratch_bytes(B, self.L1, self.L2, self.L3, self.C)),), **u8)
         self.ste_scratch = torch.empty((max(16, lib.load().nnue_ste_conv_backward_scratch(B, self.fps, self.gh, self.gw)),), **u8)
         self.sgd_scratch = torch.empty((lib.sgd_scratch_bytes(self.layout.count),), **u8)
         self.steps_done = 0
@@ -173,7 +174,7 @@ class NnueTrainer:
         p = self.p
         return [p[f"classifier.classifier.{i}.{n}"] for i in (0, 2, 4) for n in ("weight", "bias")]
 
-    def _forward(self) -> None:
+    def _features(self) -> None:
         p = self.p
         lib.conv3x3_forward(self.images, p["conv.weight"], self.stride, out=self.conv_out)
         if self.use_bits:
@@ -182,18 +183,20 @@ class NnueTrainer:
         else:
             lib.binarize_features(self.conv_out, p["visual_threshold"], self.F, act=self.act)
             lib.ft_forward(p["input.weight"], p["input.bias"], self.act, out=self.ft)
+
+    def _forward(self) -> None:
+        self._features()
         lib.classifier_forward(self.ft, True, *self._cls_params(), self.clip, scratch=self.cls_scratch,
                                out=(self.h1, self.h2, self.logits))
 
     def _local_step(self) -> None:
         """forward + loss + backward into the flat gradient buffer (every element is overwritten)."""
         p, g = self.p, self.g
-        self._forward()
-        lib.cross_entropy(self.logits, self.labels, 1.0, out=(self.sample_loss, self.loss, self.d_logits))
-        w1, _, w2, _, w3, _ = self._cls_params()
+        self._features()
         cls_grads = tuple(g[f"classifier.classifier.{i}.{n}"] for i in (0, 2, 4) for n in ("weight", "bias"))
-        lib.classifier_backward(self.ft, True, w1, w2, w3, self.h1, self.h2, self.d_logits, self.clip,
-                                scratch=self.cls_scratch, grads=cls_grads, d_x=self.d_ft)
+        lib.classifier_train_step(self.ft, True, *self._cls_params(), self.labels, 1.0, self.clip, scratch=self.cls_scratch,
+                                  out=(self.h1, self.h2, self.logits), loss_out=(self.sample_loss, self.loss),
+                                  grads=cls_grads, d_x=self.d_ft)
         if self.use_bits:
             lib.ftb_backward_weight(self.d_ft, self.bits, d_weight=g["input.weight"], d_bias=g["input.bias"])
             lib.ftb_backward_values(self.d_ft, p["input.weight"], self.bits, dst=self.d_conv_out)

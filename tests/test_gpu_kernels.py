@@ -254,3 +254,31 @@ def test_sgd_step(hip, count):
     q = g(p0.clone())
     hip.sgd_step(q, g(torch.ones(count)), None, 0.1, 0.0, 0.0, 0.0, 1.0, True, None, scratch)
     assert_close_grad(q, p0 - 0.1, "plain sgd", rtol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(3, 32, 4, 4, 10), (5, 24, 7, 5, 3), (512, 1024, 128, 32, 10), (100, 1024, 128, 32, 1000), (33, 256, 48, 16, 7)])
+@pytest.mark.parametrize("clip", (0.0, 0.75))
+def test_classifier_train_step_equals_separate_calls(hip, shape, clip):
+    """The fused training entry point (narrow layers + loss + their backward in one kernel) against
+    nnue_classifier_forward -> nnue_cross_entropy -> nnue_classifier_backward, and against the oracle."""
+    b, l1, l2, l3, c = shape
+    gen = torch.Generator().manual_seed(sum(shape) + 1)
+    x = g(torch.randn(b, l1, generator=gen))
+    mk = lambda *s: torch.randn(*s, generator=gen) / (s[-1] ** 0.5)  # noqa: E731
+    p = [g(t) for t in (mk(l2, l1), mk(l2) * 0.1, mk(l3, l2), mk(l3) * 0.1, mk(c, l3), mk(c) * 0.1)]
+    labels = g(torch.randint(0, c, (b,), generator=gen))
+    h1, h2, logits = hip.classifier_forward(x, True, *p, clip)
+    sample, loss, d_logits = hip.cross_entropy(logits, labels, 0.5)
+    d_x, grads = hip.classifier_backward(x, True, p[0], p[2], p[4], h1, h2, d_logits, clip)
+    (f1, f2, flog), (fsample, floss), fd_x, fgrads = hip.classifier_train_step(x, True, *p, labels, 0.5, clip)
+    assert_close_logits(flog, logits, "logits", rtol=1e-5)
+    assert_close_logits(f1, h1, "h1", rtol=1e-5)
+    assert_close_logits(f2, h2, "h2", rtol=1e-5)
+    assert_close_logits(fsample, sample, "sample loss", rtol=1e-5)
+    assert abs(float(floss) - float(loss)) <= 1e-5 * max(1.0, abs(float(loss)))
+    assert_close_grad(fd_x, d_x, "d_x", rtol=2e-5)
+    for a, r, nm in zip(fgrads, grads, ("d_w1", "d_b1", "d_w2", "d_b2", "d_w3", "d_b3")):
+        assert_close_grad(a, r, nm, rtol=2e-5)
+    ref_loss, _ = orc.cross_entropy_backward(orc.classifier_forward(orc.pairwise(x.cpu().double()), *[t.cpu().double() for t in p],
+                                                                    clip=clip if clip > 0 else None), labels.cpu())
+    assert abs(float(floss) - float(ref_loss)) <= 1e-4 * max(1.0, abs(float(ref_loss)))
