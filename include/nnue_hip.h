@@ -133,10 +133,12 @@ int nnue_ft_backward_values(const float* d_out, const float* weight,
  *     maskT[f*bw64 + w]  uint64  bit (b & 63) of word b >> 6 = sample b selects table row f (f < F-1: its
  *                                own position; f = F-1: sink[b] != 0; f = F: every sample -- the bias row)
  *     sink[b]            float   number of active positions >= F-1 (they all clamp to row F-1, nnue.py:701)
- * (pw64, bw64 even) and, per output and per tile of 128 staged rows, a padded byte list of the rows to add:
- *     tlW [B][tiles_fwd][128] / tcW [B][tiles_fwd]       sample b   x table-row tile  -> local row indices
- *     tlT [F+1][tiles_bwd][128] / tcT [F+1][tiles_bwd]   output row x batch tile      -> local sample indices
- * (ascending, padded with 128 = an all-zero row; entry e at byte ((e>>2)&3)*32 + (e>>4)*4 + (e&3)).
+ * (pw64, bw64 even) and, per output and per tile of 128 staged rows, a padded list of the rows to add:
+ *     tlW [B][tiles_fwd][128] u16 / tcW [B][tiles_fwd] u8       sample b   x table-row tile
+ *     tlT [F+1][tiles_bwd][128] u16 / tcT [F+1][tiles_bwd] u8   output row x batch tile
+ * Entries are LDS byte offsets (local row or sample index * 256), ascending, padded with 32768 (= an all-zero
+ * row); entry e sits in slot ((e>>2)&3)*32 + (e>>4)*4 + (e&3); tc holds the entry count.  The list buffers
+ * are passed as uint8_t* (256 bytes per record).
  * A workgroup stages a tile of the table (or of d_out) in LDS once and all its samples (rows) gather from
  * LDS, so memory-side traffic is the table once per sample tile instead of once per sample.  L1 must be 256,
  * 512 or 1024 (nnue_ftb_supported); other widths use the list kernels above. */

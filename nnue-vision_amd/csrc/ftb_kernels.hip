@@ -16,10 +16,10 @@
 //   maskW [B][pw64] u64      bit p of sample b (flat position bits)
 //   maskT [F+1][bw64] u64    bit b of table row f; row F-1 = (sink[b] != 0), row F = every sample (bias)
 //   sink  [B] float
-//   tile lists  tl [R][NT][128] u8 + tc [R][NT] u8: for output r and tile t (128 staged rows) the local
-//               indices (0..127) of the staged rows to add, ascending, padded with 128 (= an all-zero LDS
-//               row).  Entry e sits at byte ((e>>2)&3)*32 + (e>>4)*4 + (e&3): lane group g of a wave reads
-//               its entries {16c + 4g + k} as 32 contiguous bytes.
+//   tile lists  tl [R][NT][128] u16 + tc [R][NT] u8: for output r and tile t (128 staged rows) the LDS byte
+//               offsets (local row * 256) of the staged rows to add, ascending, padded with 32768 (= an
+//               all-zero LDS row).  Entry e sits at slot ((e>>2)&3)*32 + (e>>4)*4 + (e&3): lane group g of a
+//               wave reads its entries {16c + 4g + k} as 64 contiguous bytes.
 //     forward lists  : R = B samples,      tiles over table rows   (tlW / tcW)
 //     backward lists : R = F + 1 outputs,  tiles over batch samples (tlT / tcT)
 #include "common.h"
@@ -30,20 +30,20 @@ using u64 = unsigned long long;
 
 constexpr int kTC = 64;                       // columns per workgroup: 16 lanes x float4
 constexpr int kRT = 128;                      // staged rows per LDS tile
-constexpr int kTileFloats = kRT * kTC + kTC;  // + the all-zero row (index kRT)
-constexpr int kWaves = 8;                     // waves per gather workgroup
+constexpr int kWaves = 16;                    // waves per gather workgroup (4 per SIMD)
+constexpr int kRecBytes = kRT * 2;            // one list record: 128 u16 offsets
 
 __device__ __forceinline__ int list_pos(int e) { return ((e >> 2) & 3) * 32 + (e >> 4) * 4 + (e & 3); }
 
 // Writes the tile list of one (output, tile) from its two 64-bit membership words.  One wave; lane = bit.
-__device__ __forceinline__ void emit_tile_list(u64 m0, u64 m1, int lane, unsigned char* __restrict__ lst,
+__device__ __forceinline__ void emit_tile_list(u64 m0, u64 m1, int lane, unsigned short* __restrict__ lst,
                                                unsigned char* __restrict__ cnt_out) {
   const u64 lt = (1ull << lane) - 1ull;
   const int c0 = __popcll(m0), cnt = c0 + __popcll(m1);
-  if ((m0 >> lane) & 1ull) lst[list_pos(__popcll(m0 & lt))] = (unsigned char)lane;
-  if ((m1 >> lane) & 1ull) lst[list_pos(c0 + __popcll(m1 & lt))] = (unsigned char)(64 + lane);
-  if (lane >= cnt) lst[list_pos(lane)] = (unsigned char)kRT;  // padding -> zero row
-  if (64 + lane >= cnt) lst[list_pos(64 + lane)] = (unsigned char)kRT;
+  if ((m0 >> lane) & 1ull) lst[list_pos(__popcll(m0 & lt))] = (unsigned short)(lane * (kTC * 4));
+  if ((m1 >> lane) & 1ull) lst[list_pos(c0 + __popcll(m1 & lt))] = (unsigned short)((64 + lane) * (kTC * 4));
+  if (lane >= cnt) lst[list_pos(lane)] = (unsigned short)(kRT * kTC * 4);  // padding -> zero row
+  if (64 + lane >= cnt) lst[list_pos(64 + lane)] = (unsigned short)(kRT * kTC * 4);
   if (lane == 0) *cnt_out = (unsigned char)cnt;
 }
 
@@ -52,7 +52,7 @@ __device__ __forceinline__ void emit_tile_list(u64 m0, u64 m1, int lane, unsigne
 __global__ __launch_bounds__(256) void bits_rows_kernel(const float* __restrict__ conv_out,
                                                         const float* __restrict__ thr, int G, int P, int F,
                                                         u64* __restrict__ maskW, int pw64, float* __restrict__ sink,
-                                                        int* __restrict__ n, unsigned char* __restrict__ tlW,
+                                                        int* __restrict__ n, unsigned short* __restrict__ tlW,
                                                         unsigned char* __restrict__ tcW, int ntW) {
   __shared__ int cnt_s[4], sink_s[4];
   const int b = blockIdx.x;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void bits_transpose_kernel(const float* __rest
                                                              const float* __restrict__ thr,
                                                              const float* __restrict__ sink, int B, int G, int P,
                                                              int F, u64* __restrict__ maskT, int bw64,
-                                                             unsigned char* __restrict__ tlT,
+                                                             unsigned short* __restrict__ tlT,
                                                              unsigned char* __restrict__ tcT, int ntT) {
   __shared__ unsigned char tile[128][kTrRows + 4];
   const int f0 = blockIdx.x * kTrRows, b0 = blockIdx.y * 128;
@@ -129,128 +129,172 @@ __global__ __launch_bounds__(256) void bits_transpose_kernel(const float* __rest
 // MODE 0 (forward):     outputs = samples,    staged rows = table rows, lists tlW; bias + valued sink row
 // MODE 1 (weight grad): outputs = table rows + bias row, staged rows = d_out rows, lists tlT; row F-1 valued by sink[]
 //
-// Workgroup = 8 waves x SW outputs each, 64 columns (grid.y), a slice of the tiles (grid.z).  The staged
-// matrix streams through two 32 KB LDS buffers (loads for tile t+1 are issued before tile t is consumed).
-// Control flow is wave-uniform: a wave works on ONE output at a time; its four 16-lane groups fetch four
-// DIFFERENT staged rows with one ds_read_b128 (1 KiB), indices coming from list bytes that were loaded
-// one tile ahead.  Each lane group therefore holds a partial sum over every 4th-of-16 entries; the four
-// partials are combined in a fixed order at the end.
-template <int SW, int MODE>
-__global__ __launch_bounds__(512) void ftb_gather_kernel(const float* __restrict__ src,   // [n_src][L1]
-                                                         const float* __restrict__ bias,  // MODE 0
-                                                         const unsigned char* __restrict__ tl,
-                                                         const unsigned char* __restrict__ tc, int nt,
-                                                         const float* __restrict__ sink, int n_out, int n_src,
-                                                         int sink_row, int L1, int tiles_per_split,
-                                                         float* __restrict__ out, float* __restrict__ out_extra,
-                                                         float* __restrict__ slabs) {
-  __shared__ __attribute__((aligned(16))) float tile[2][kTileFloats];
-  __shared__ float coef_t[2][kRT + 1];  // MODE 1: sink[] of the staged samples (+ 0 for the zero row)
+// Workgroup = 8 waves x SW outputs each, 64 columns (grid.y), a slice of the tiles (grid.z).
+//
+// Staging is asynchronous LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write): a ring of NBUF slots,
+// each holding one tile = 128 staged rows x 256 B, the 128-byte list records of the workgroup's outputs for
+// that tile and (MODE 1) the staged samples' sink values.  With NBUF = 3 two tiles are always in flight while a
+// third is consumed; arrival is tracked with a counted s_waitcnt vmcnt and ONE raw s_barrier per tile -- the
+// loop contains no ordinary global load, so nothing drains the DMA queue early.  NBUF = 1 (single-tile
+// problems) trades the ring for three workgroups per CU.
+//
+// Consumption is wave-uniform: a wave works on ONE output at a time; its four 16-lane groups fetch four
+// DIFFERENT staged rows with one ds_read_b128 (1 KiB).  Each lane group therefore holds a partial sum over
+// its quarter of the entries; the four partials are combined in a fixed order at the end.
+constexpr int kSlotData = kRT * kTC * 4 + kTC * 4;  // 128 rows + the all-zero row, bytes
+constexpr int kCoefBytes = 528;                     // 129 floats, padded
+
+__device__ __forceinline__ void dma16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+__device__ __forceinline__ void dma4(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 4, 0, 0);
+}
+
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+template <int SW, int MODE, int NBUF>
+__global__ __launch_bounds__(1024) void ftb_gather_kernel(const float* __restrict__ src,   // [n_src][L1]
+                                                          const float* __restrict__ bias,  // MODE 0
+                                                          const unsigned short* __restrict__ tl, int nt,
+                                                          const float* __restrict__ sink, int n_out, int n_src,
+                                                          int sink_row, int L1, int tiles_per_split,
+                                                          float* __restrict__ out, float* __restrict__ out_extra,
+                                                          float* __restrict__ slabs) {
+  constexpr int kListBytes = kWaves * SW * kRecBytes;  // list records of one tile (SW * 4 KiB)
+  constexpr int kListPieces = kListBytes / 1024;       // 1 KiB DMA pieces: 4 * SW
+  constexpr int kSlot = kSlotData + kListBytes + (MODE == 1 ? kCoefBytes : 0);
+  __shared__ __attribute__((aligned(16))) char lds[NBUF * kSlot];  // ONE shared object (see guide: glds + 2nd object)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = lane >> 4, l16 = lane & 15;
   const int col = blockIdx.y * kTC + l16 * 4;
-  const int o0 = (blockIdx.x * kWaves + wave) * SW;
+  const int obase = blockIdx.x * kWaves * SW;
+  const int o0 = obase + wave * SW;
   const int t_lo = blockIdx.z * tiles_per_split;
   const int t_hi = min(nt, t_lo + tiles_per_split);
+  // DMA instructions this wave issues per tile: 2 data pieces (+1 list piece, +1 coefficient piece)
+  const bool lists_mine = wave < kListPieces;
+  const bool coef_mine = (MODE == 1) && wave >= kWaves - 2;
 
-  float4 acc[SW];
-#pragma unroll
-  for (int s = 0; s < SW; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (tid < 2 * (kTC / 4)) {
-    reinterpret_cast<float4*>(&tile[tid / (kTC / 4)][kRT * kTC])[tid % (kTC / 4)] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < 2) coef_t[tid][kRT] = 0.f;
+  for (int b = 0; b < NBUF; ++b) {  // zero rows (index kRT) and the zero coefficient, never overwritten by DMA
+    if (tid < kTC / 4) reinterpret_cast<float4*>(lds + b * kSlot + kRT * kTC * 4)[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE == 1 && tid == 0) reinterpret_cast<float*>(lds + b * kSlot + kSlotData + kListBytes)[kRT] = 0.f;
   }
-  const int srow = tid >> 4, scol = (tid & 15) * 4;  // staging role: 32 rows x 64 columns per pass, 4 passes
 
-  float4 st[4];
-  float st_coef = 0.f;
-  auto stage_load = [&](int t) {
+  auto issue_tile = [&](int t, int slot) {
+    char* base = lds + slot * kSlot;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = t * kRT + srow + 32 * i;
-      st[i] = (r < n_src) ? *reinterpret_cast<const float4*>(src + (size_t)r * L1 + blockIdx.y * kTC + scol)
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < 2; ++i) {  // one piece = 4 staged rows x 256 B = 1 KiB, lane-linear in LDS
+      const int piece = wave * 2 + i;
+      int r = t * kRT + piece * 4 + (lane >> 4);
+      r = r < n_src ? r : n_src - 1;  // rows past the end are never referenced by a list
+      dma16(src + (size_t)r * L1 + blockIdx.y * kTC + l16 * 4, base + piece * 1024);
     }
-    if (MODE == 1 && tid < kRT) st_coef = (t * kRT + tid < n_src) ? sink[t * kRT + tid] : 0.f;
-  };
-  auto stage_store = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&tile[buf][(srow + 32 * i) * kTC + scol]) = st[i];
-    if (MODE == 1 && tid < kRT) coef_t[buf][tid] = st_coef;
-  };
-  // list bytes of this lane group for output s, tile t: 2 x uint4 = its 32 entries (8 chunks x 4)
-  auto load_list = [&](int t, uint4 (&lo)[SW], uint4 (&hi)[SW], int (&cnt)[SW]) {
-#pragma unroll
-    for (int s = 0; s < SW; ++s) {
-      const int o = o0 + s;
-      if (o < n_out) {
-        const unsigned char* p = tl + ((size_t)o * nt + t) * kRT + grp * 32;
-        lo[s] = *reinterpret_cast<const uint4*>(p);
-        hi[s] = *reinterpret_cast<const uint4*>(p + 16);
-        cnt[s] = tc[(size_t)o * nt + t];
-      } else {
-        cnt[s] = 0;
-      }
+    if (lists_mine) {  // piece = 4 list records of 256 B
+      int rec = obase + wave * 4 + (lane >> 4);
+      rec = rec < n_out ? rec : n_out - 1;
+      dma16(reinterpret_cast<const char*>(tl) + ((size_t)rec * nt + t) * kRecBytes + l16 * 16, base + kSlotData + wave * 1024);
+    }
+    if (coef_mine) {
+      const int h = wave - (kWaves - 2);
+      int r = t * kRT + h * 64 + lane;
+      r = r < n_src ? r : n_src - 1;
+      dma4(sink + r, base + kSlotData + kListBytes + h * 256);
     }
   };
+  auto wait_tiles_in_flight = [&](bool one_behind) {  // returns when every DMA except the youngest tile's has landed
+    if (!one_behind) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (lists_mine && coef_mine) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else if (lists_mine || coef_mine) {
+      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    }
+  };
 
-  uint4 lo[SW], hi[SW], nlo[SW], nhi[SW];
-  int cnt[SW], ncnt[SW];
-  if (t_lo < t_hi) {
-    stage_load(t_lo);
-    load_list(t_lo, lo, hi, cnt);
-    stage_store(0);
-  }
-  __syncthreads();
+  f32x2 acc[SW][2];
+#pragma unroll
+  for (int s = 0; s < SW; ++s) acc[s][0] = acc[s][1] = (f32x2){0.f, 0.f};
+
+  if (t_lo < t_hi) issue_tile(t_lo, 0);
+  if (NBUF > 1 && t_lo + 1 < t_hi) issue_tile(t_lo + 1, 1);
   for (int t = t_lo; t < t_hi; ++t) {
-    const int buf = (t - t_lo) & 1;
-    if (t + 1 < t_hi) {
-      stage_load(t + 1);
-      load_list(t + 1, nlo, nhi, ncnt);
-    }
-    const char* __restrict__ tb = reinterpret_cast<const char*>(&tile[buf][0]) + l16 * 16;
+    const int slot = (NBUF > 1) ? (t - t_lo) % NBUF : 0;
+    wait_tiles_in_flight(NBUF > 1 && t + 1 < t_hi);
+    __builtin_amdgcn_s_barrier();  // tile t is complete in LDS; every wave is done with tile t-1
+    asm volatile("" ::: "memory");
+    if (NBUF > 1 && t + 2 < t_hi) issue_tile(t + 2, (t + 2 - t_lo) % NBUF);  // refills the slot tile t-1 used
+    const char* __restrict__ sb = lds + slot * kSlot;
+    const char* __restrict__ tb = sb + l16 * 16;
+    const float* __restrict__ coef_t = reinterpret_cast<const float*>(sb + kSlotData + kListBytes);
+    // Outputs are consumed G = 2 at a time, chunk by chunk: 8 ds_read_b128 in flight per wave, 16 waves per
+    // CU, and the register count stays under the 128 a 1024-thread workgroup may use.  A list that has ended
+    // keeps reading the zero row.
+    constexpr int G = SW < 2 ? SW : 2;
+    constexpr unsigned kPad = 0x80008000u;  // two padding offsets (32768)
 #pragma unroll
-    for (int s = 0; s < SW; ++s) {
-      const int c = __builtin_amdgcn_readfirstlane(cnt[s]);
-      const bool valued = (MODE == 1) && (o0 + s == sink_row);  // wave-uniform
-      const unsigned words[8] = {lo[s].x, lo[s].y, lo[s].z, lo[s].w, hi[s].x, hi[s].y, hi[s].z, hi[s].w};
+    for (int s0 = 0; s0 < SW; s0 += G) {
+      if (o0 + s0 >= n_out) break;  // wave-uniform
+      unsigned words[G][16];
+      bool valued[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const bool live = o0 + s0 + g < n_out;  // wave-uniform
+        valued[g] = (MODE == 1) && (o0 + s0 + g == sink_row);
+        const uint4* rec = reinterpret_cast<const uint4*>(sb + kSlotData + (wave * SW + s0 + g) * kRecBytes + grp * 64);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint4 w = rec[q];
+          words[g][4 * q + 0] = live ? w.x : kPad; words[g][4 * q + 1] = live ? w.y : kPad;
+          words[g][4 * q + 2] = live ? w.z : kPad; words[g][4 * q + 3] = live ? w.w : kPad;
+        }
+      }
 #pragma unroll
       for (int ch = 0; ch < 8; ++ch) {
-        if (ch * 16 >= c) break;  // wave-uniform
-        const unsigned e = words[ch];
-        const unsigned j0 = e & 0xffu, j1 = (e >> 8) & 0xffu, j2 = (e >> 16) & 0xffu, j3 = e >> 24;
-        const float4 v0 = *reinterpret_cast<const float4*>(tb + j0 * (kTC * 4));
-        const float4 v1 = *reinterpret_cast<const float4*>(tb + j1 * (kTC * 4));
-        const float4 v2 = *reinterpret_cast<const float4*>(tb + j2 * (kTC * 4));
-        const float4 v3 = *reinterpret_cast<const float4*>(tb + j3 * (kTC * 4));
-        if (!valued) {
-          acc[s].x += v0.x; acc[s].y += v0.y; acc[s].z += v0.z; acc[s].w += v0.w;
-          acc[s].x += v1.x; acc[s].y += v1.y; acc[s].z += v1.z; acc[s].w += v1.w;
-          acc[s].x += v2.x; acc[s].y += v2.y; acc[s].z += v2.z; acc[s].w += v2.w;
-          acc[s].x += v3.x; acc[s].y += v3.y; acc[s].z += v3.z; acc[s].w += v3.w;
-        } else {
-          const float c0 = coef_t[buf][j0], c1 = coef_t[buf][j1], c2 = coef_t[buf][j2], c3 = coef_t[buf][j3];
-          acc[s].x = fmaf(c0, v0.x, acc[s].x); acc[s].y = fmaf(c0, v0.y, acc[s].y); acc[s].z = fmaf(c0, v0.z, acc[s].z); acc[s].w = fmaf(c0, v0.w, acc[s].w);
-          acc[s].x = fmaf(c1, v1.x, acc[s].x); acc[s].y = fmaf(c1, v1.y, acc[s].y); acc[s].z = fmaf(c1, v1.z, acc[s].z); acc[s].w = fmaf(c1, v1.w, acc[s].w);
-          acc[s].x = fmaf(c2, v2.x, acc[s].x); acc[s].y = fmaf(c2, v2.y, acc[s].y); acc[s].z = fmaf(c2, v2.z, acc[s].z); acc[s].w = fmaf(c2, v2.w, acc[s].w);
-          acc[s].x = fmaf(c3, v3.x, acc[s].x); acc[s].y = fmaf(c3, v3.y, acc[s].y); acc[s].z = fmaf(c3, v3.z, acc[s].z); acc[s].w = fmaf(c3, v3.w, acc[s].w);
+        bool any_live = false;
+#pragma unroll
+        for (int g = 0; g < G; ++g) any_live |= words[g][2 * ch] != kPad;  // a chunk's first pair is padding only if all of it is
+        if (!__any(any_live)) break;  // both lists have ended
+        float4 v[G][4];
+        unsigned off[G][4];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const unsigned e0 = words[g][2 * ch], e1 = words[g][2 * ch + 1];
+          off[g][0] = e0 & 0xffffu; off[g][1] = e0 >> 16; off[g][2] = e1 & 0xffffu; off[g][3] = e1 >> 16;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[g][k] = *reinterpret_cast<const float4*>(tb + off[g][k]);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          if (!valued[g]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              acc[s0 + g][0] += (f32x2){v[g][k].x, v[g][k].y};
+              acc[s0 + g][1] += (f32x2){v[g][k].z, v[g][k].w};
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float c = coef_t[off[g][k] >> 8];
+              acc[s0 + g][0] += (f32x2){c * v[g][k].x, c * v[g][k].y};
+              acc[s0 + g][1] += (f32x2){c * v[g][k].z, c * v[g][k].w};
+            }
+          }
         }
       }
     }
-    if (t + 1 < t_hi) stage_store(buf ^ 1);
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < SW; ++s) {
-      lo[s] = nlo[s];
-      hi[s] = nhi[s];
-      cnt[s] = ncnt[s];
-    }
+    if (NBUF == 1) __builtin_amdgcn_s_barrier();  // single slot: everyone is done before it is refilled
+    if (NBUF == 1 && t + 1 < t_hi) issue_tile(t + 1, 0);
   }
   // combine the four lane-group partials (fixed order), then lanes 0..15 hold the 64-column result
 #pragma unroll
   for (int s = 0; s < SW; ++s) {
-    float4 a = acc[s];
+    float4 a = make_float4(acc[s][0].x, acc[s][0].y, acc[s][1].x, acc[s][1].y);
     a.x += __shfl_xor(a.x, 16); a.y += __shfl_xor(a.y, 16); a.z += __shfl_xor(a.z, 16); a.w += __shfl_xor(a.w, 16);
     a.x += __shfl_xor(a.x, 32); a.y += __shfl_xor(a.y, 32); a.z += __shfl_xor(a.z, 32); a.w += __shfl_xor(a.w, 32);
     const int o = o0 + s;
@@ -315,6 +359,7 @@ __global__ __launch_bounds__(256) void ftb_finish_kernel(const float* __restrict
 // ahead together with the sample's mask word), the set bits of the 16-bit mask slice pick LDS rows, the dot
 // products are transposed-and-reduced across the wave with a butterfly, and ranks map them back to bit
 // positions, so the RB outputs leave as ONE coalesced store (zeros included: no separate zero fill).
+constexpr int kValWaves = 8;  // waves per value-gradient workgroup
 template <int S>
 __global__ __launch_bounds__(512) void ftb_values_kernel(const float* __restrict__ d_out,
                                                          const float* __restrict__ W,
@@ -322,7 +367,7 @@ __global__ __launch_bounds__(512) void ftb_values_kernel(const float* __restrict
                                                          int P, int samples_per_block, float* __restrict__ dst) {
   constexpr int L1 = 256 * S;
   constexpr int RB = 16;  // rows per workgroup = one butterfly round
-  __shared__ __attribute__((aligned(16))) float rows[RB * L1];
+  __shared__ __attribute__((aligned(16))) float rows[(RB + 1) * L1];  // + an all-zero row
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool has_sink = F - 1 < P;              // ids >= F-1 exist and fold into row F-1
   const int p_lim = has_sink ? F - 1 : P;       // positions below p_lim have a table row of their own
@@ -333,6 +378,7 @@ __global__ __launch_bounds__(512) void ftb_values_kernel(const float* __restrict
     const int r = i / (L1 / 4), c4 = i - r * (L1 / 4);
     reinterpret_cast<float4*>(rows)[i] = *reinterpret_cast<const float4*>(W + (size_t)(r0 + r) * L1 + c4 * 4);
   }
+  for (int i = tid; i < L1 / 4; i += 512) reinterpret_cast<float4*>(rows + RB * L1)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
   const bool sink_block = has_sink && (F - 1 >= r0) && (F - 1 < r0 + RB);
   const int b_lo = blockIdx.x * samples_per_block;
@@ -350,8 +396,8 @@ __global__ __launch_bounds__(512) void ftb_values_kernel(const float* __restrict
     for (int s = 0; s < S; ++s) g[s] = *reinterpret_cast<const float4*>(d_out + (size_t)b * L1 + s * 256 + lane * 4);
     word = maskW[(size_t)b * pw64 + (r0 >> 6)];
   }
-  for (; b < b_hi; b += kWaves) {
-    const int bn = b + kWaves;
+  for (; b < b_hi; b += kValWaves) {
+    const int bn = b + kValWaves;
     if (bn < b_hi) {
 #pragma unroll
       for (int s = 0; s < S; ++s) gn[s] = *reinterpret_cast<const float4*>(d_out + (size_t)bn * L1 + s * 256 + lane * 4);
@@ -360,24 +406,33 @@ __global__ __launch_bounds__(512) void ftb_values_kernel(const float* __restrict
     const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(word >> (r0 & 63))) & keep;
     float p[RB];
     unsigned mm = m;
+    const int cnt = __popc(m);
 #pragma unroll
-    for (int u = 0; u < RB; ++u) {
-      float a = 0.f;
-      if (mm != 0) {  // wave-uniform
-        const int j = __builtin_ctz(mm);
-        mm &= mm - 1;
-        const float* __restrict__ wr = rl + j * L1;
-        float part[S];
+    for (int u0 = 0; u0 < RB; u0 += 4) {
+      if (u0 >= cnt) {  // wave-uniform: nothing left
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-          const float4 v = *reinterpret_cast<const float4*>(wr + s * 256);
-          part[s] = fmaf(v.w, g[s].w, fmaf(v.z, g[s].z, fmaf(v.y, g[s].y, v.x * g[s].x)));
-        }
-        a = part[0];
-#pragma unroll
-        for (int s = 1; s < S; ++s) a += part[s];
+        for (int u = 0; u < 4; ++u) p[u0 + u] = 0.f;
+        continue;
       }
-      p[u] = a;
+      // four entries at a time, no branches inside: entries past the end read the all-zero row RB
+      int j[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        j[u] = mm ? __builtin_ctz(mm) : RB;
+        mm &= mm - 1;
+      }
+      float4 v[4][S];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int s = 0; s < S; ++s) v[u][s] = *reinterpret_cast<const float4*>(rl + j[u] * L1 + s * 256);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float a = 0.f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) a += fmaf(v[u][s].w, g[s].w, fmaf(v[u][s].z, g[s].z, fmaf(v[u][s].y, g[s].y, v[u][s].x * g[s].x)));
+        p[u0 + u] = a;
+      }
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -436,26 +491,27 @@ struct GatherPlan {
 
 GatherPlan plan_gather(int n_out, int nt, int col_tiles) {
   // Outputs per wave (SW): more outputs per staged tile = less staging traffic, as long as about one
-  // workgroup per CU remains.  When the outputs alone cannot fill the chip and there are many tiles
-  // (big tables), keep SW = 4 and split the tiles over grid.z instead (partial slabs + a finish pass).
+  // workgroup per CU remains (the ring version runs one 16-wave workgroup per CU).  When the outputs alone
+  // cannot fill the chip and there are many tiles (big tables), keep SW = 2 and split the tiles over grid.z
+  // instead (partial slabs + a finish pass).
   GatherPlan p{4, 1, nt > 0 ? nt : 1};
   auto groups = [&](int sw) { return (long long)((n_out + kWaves * sw - 1) / (kWaves * sw)) * col_tiles; };
-  if (groups(4) < 192 && nt >= 8) {
-    int want = (int)((256 + groups(4) - 1) / groups(4));
+  if (groups(2) < 192 && nt >= 8) {
+    p.sw = 2;
+    int want = (int)((256 + groups(2) - 1) / groups(2));
     if (want > nt / 2) want = nt / 2;
     if (want > 16) want = 16;
     p.tiles_per_split = (nt + want - 1) / want;
     p.splits = (nt + p.tiles_per_split - 1) / p.tiles_per_split;
     return p;
   }
-  while (p.sw > 1 && groups(p.sw) < 448) p.sw >>= 1;  // ~2 workgroups per CU: one stages while the other gathers
+  while (p.sw > 1 && groups(p.sw) < 200) p.sw >>= 1;
   return p;
 }
 
 template <int MODE>
-int launch_gather(hipStream_t s, const float* src, const float* bias, const unsigned char* tl, const unsigned char* tc, int nt,
-                  const float* sink, int n_out, int n_src, int sink_row, int L1, float* out, float* extra, void* scratch,
-                  int64_t scratch_bytes, const char* who) {
+int launch_gather(hipStream_t s, const float* src, const float* bias, const unsigned short* tl, int nt, const float* sink, int n_out,
+                  int n_src, int sink_row, int L1, float* out, float* extra, void* scratch, int64_t scratch_bytes, const char* who) {
   const int col_tiles = L1 / kTC;
   const GatherPlan p = plan_gather(n_out, nt, col_tiles);
   float* slabs = nullptr;
@@ -466,13 +522,20 @@ int launch_gather(hipStream_t s, const float* src, const float* bias, const unsi
     NNUE_REQUIRE(nnue_aligned16(scratch), NNUE_E_ARG, "%s: scratch must be 16-byte aligned", who);
     slabs = static_cast<float*>(scratch);
   }
-  const dim3 grid((n_out + kWaves * p.sw - 1) / (kWaves * p.sw), col_tiles, p.splits), block(512);
-#define NNUE_LAUNCH_GATHER(SWV)                                                                                          \
-  hipLaunchKernelGGL((ftb_gather_kernel<SWV, MODE>), grid, block, 0, s, src, bias, tl, tc, nt, sink, n_out, n_src, sink_row, L1, \
+  const dim3 grid((n_out + kWaves * p.sw - 1) / (kWaves * p.sw), col_tiles, p.splits), block(64 * kWaves);
+  const bool ring = p.tiles_per_split > 1;  // single-tile problems: one slot, three workgroups per CU
+#define NNUE_LAUNCH_GATHER(SWV, NB)                                                                                            \
+  hipLaunchKernelGGL((ftb_gather_kernel<SWV, MODE, NB>), grid, block, 0, s, src, bias, tl, nt, sink, n_out, n_src, sink_row, L1, \
                      p.tiles_per_split, out, extra, slabs)
-  if (p.sw == 4) NNUE_LAUNCH_GATHER(4);
-  else if (p.sw == 2) NNUE_LAUNCH_GATHER(2);
-  else NNUE_LAUNCH_GATHER(1);
+#define NNUE_LAUNCH_GATHER_SW(SWV) \
+  do {                             \
+    if (ring) NNUE_LAUNCH_GATHER(SWV, 3); \
+    else NNUE_LAUNCH_GATHER(SWV, 1);      \
+  } while (0)
+  if (p.sw == 4) NNUE_LAUNCH_GATHER_SW(4);
+  else if (p.sw == 2) NNUE_LAUNCH_GATHER_SW(2);
+  else NNUE_LAUNCH_GATHER_SW(1);
+#undef NNUE_LAUNCH_GATHER_SW
 #undef NNUE_LAUNCH_GATHER
   if (p.splits > 1) {
     const long long q = (long long)n_out * (L1 / 4);
@@ -525,9 +588,9 @@ extern "C" int nnue_binarize_bits(const float* conv_out, const float* thr, int B
   nnue_ftb_list_tiles(B, F, P, &ntf, &ntb);
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(bits_rows_kernel, dim3(B), dim3(256), 0, s, conv_out, thr, Gh * Gw, P, F, reinterpret_cast<u64*>(maskW), pw64,
-                     sink, n, tlW, tcW, ntf);
+                     sink, n, reinterpret_cast<unsigned short*>(tlW), tcW, ntf);
   hipLaunchKernelGGL(bits_transpose_kernel, dim3((F + 1 + kTrRows - 1) / kTrRows, ntb), dim3(256), 0, s, conv_out, thr, sink, B, Gh * Gw, P, F,
-                     reinterpret_cast<u64*>(maskT), bw64, tlT, tcT, ntb);
+                     reinterpret_cast<u64*>(maskT), bw64, reinterpret_cast<unsigned short*>(tlT), tcT, ntb);
   return nnue_launch_status("nnue_binarize_bits");
 }
 
@@ -542,8 +605,9 @@ extern "C" int nnue_ftb_forward(const float* weight, const float* bias, const ui
   int ntf = 0, ntb = 0;
   nnue_ftb_list_tiles(B, F, P, &ntf, &ntb);
   const int d = direct_rows(F, P);
-  return launch_gather<0>(static_cast<hipStream_t>(stream), weight, bias, tlW, tcW, ntf, sink, B, d, (F - 1 < P) ? F - 1 : -1, L1,
-                          out, nullptr, scratch, scratch_bytes, "nnue_ftb_forward");
+  (void)tcW;  // counts are implied by the padding; kept in the ABI for consumers that want them
+  return launch_gather<0>(static_cast<hipStream_t>(stream), weight, bias, reinterpret_cast<const unsigned short*>(tlW), ntf, sink, B, d, (F - 1 < P) ? F - 1 : -1, L1, out,
+                          nullptr, scratch, scratch_bytes, "nnue_ftb_forward");
 }
 
 extern "C" int nnue_ftb_backward_weight(const float* d_out, const uint8_t* tlT, const uint8_t* tcT, const float* sink, int B, int F,
@@ -558,8 +622,9 @@ extern "C" int nnue_ftb_backward_weight(const float* d_out, const uint8_t* tlT, 
   int ntf = 0, ntb = 0;
   nnue_ftb_list_tiles(B, F, P, &ntf, &ntb);
   // outputs: F table rows + the bias row; row F-1 is valued by sink[]; rows the map cannot reach have empty lists
-  return launch_gather<1>(static_cast<hipStream_t>(stream), d_out, nullptr, tlT, tcT, ntb, sink, F + 1, B, F - 1, L1, d_weight, d_bias,
-                          scratch, scratch_bytes, "nnue_ftb_backward_weight");
+  (void)tcT;
+  return launch_gather<1>(static_cast<hipStream_t>(stream), d_out, nullptr, reinterpret_cast<const unsigned short*>(tlT), ntb, sink, F + 1, B, F - 1, L1, d_weight, d_bias, scratch,
+                          scratch_bytes, "nnue_ftb_backward_weight");
 }
 
 extern "C" int nnue_ftb_backward_values(const float* d_out, const float* weight, const uint64_t* maskW, int pw64, int B,

@@ -329,9 +329,9 @@ class FeatureBits:
     maskT: torch.Tensor  # int64 [F+1, bw64]         sample bits per table row (+ bias row)
     sink: torch.Tensor   # float32 [B]               active ids >= F-1
     n: torch.Tensor      # int32 [B]                 active positions
-    tlW: torch.Tensor    # uint8 [B, tiles_fwd, 128] rows to add per sample and table tile
+    tlW: torch.Tensor    # int16 [B, tiles_fwd, 128] LDS offsets of the rows to add per sample and table tile
     tcW: torch.Tensor    # uint8 [B, tiles_fwd]
-    tlT: torch.Tensor    # uint8 [F+1, tiles_bwd, 128] samples to add per output row and batch tile
+    tlT: torch.Tensor    # int16 [F+1, tiles_bwd, 128] LDS offsets of the samples to add per output row and batch tile
     tcT: torch.Tensor    # uint8 [F+1, tiles_bwd]
     scratch: torch.Tensor  # uint8, split-slab workspace of the gather kernels
     positions: int       # P = fps*Gh*Gw
@@ -352,8 +352,8 @@ class FeatureBits:
                            torch.empty((num_rows + 1, bw64), dtype=torch.int64, device=device),
                            torch.empty((batch,), dtype=torch.float32, device=device),
                            torch.empty((batch,), dtype=torch.int32, device=device),
-                           torch.empty((batch, tf.value, 128), **u8), torch.empty((batch, tf.value), **u8),
-                           torch.empty((num_rows + 1, tb.value, 128), **u8), torch.empty((num_rows + 1, tb.value), **u8),
+                           torch.empty((batch, tf.value, 128), dtype=torch.int16, device=device), torch.empty((batch, tf.value), **u8),
+                           torch.empty((num_rows + 1, tb.value, 128), dtype=torch.int16, device=device), torch.empty((num_rows + 1, tb.value), **u8),
                            torch.empty((max(16, int(load().nnue_ftb_scratch(batch, num_rows, positions, l1))),), **u8),
                            positions, num_rows)
 

@@ -67,7 +67,9 @@ def test_bits_and_products(hip, geom, thr_scale):
         tl, tc = tl.cpu().long(), tc.cpu().long()
         e = torch.arange(128)
         pos = ((e >> 2) & 3) * 32 + (e >> 4) * 4 + (e & 3)
-        return tl[..., pos], tc  # entry order
+        off = tl[..., pos] & 0xffff  # entry order; u16 LDS offsets = local index * 256, padding 32768
+        assert bool((off % 256 == 0).all())
+        return off // 256, tc
     lw, cw = decode(bits.tlW, bits.tcW)
     for t in range(lw.shape[1]):
         seg = on[:, t * 128:(t + 1) * 128].clone()
