@@ -89,6 +89,11 @@ def cpu_baseline(cfg, budget_s):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line (the JSON): libraries that chat on fd 1 (RCCL prints a version banner
+    # at communicator creation) are sent to stderr until the result is ready
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -100,7 +105,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # under torch.distributed.run, also with one rank
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     import nnue
@@ -205,8 +210,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+        os.dup2(2, 1)
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -15,7 +15,10 @@ SGD step) is one fixed sequence of HIP kernels here, working on preallocated buf
   a hipGraph and replayed (the C ABI launches on torch's current stream);
 * data parallel = each rank takes an equal slice of the global batch; mean-loss gradients are summed
   by the all-reduce and scaled by 1/world inside the SGD kernel, where the *global* gradient norm is
-  clipped -- every rank therefore applies the identical update.
+  clipped -- every rank therefore applies the identical update.  The flat buffer is reduced in two
+  buckets: everything except the threshold / conv-weight gradients (99.98 % of the bytes) is ready
+  once the FT weight gradient is done and is all-reduced WHILE the value-gradient and STE/conv
+  backward kernels run; only the 232-float tail bucket is exposed.
 
 ``FlatLayout`` and ``DataParallel`` are device-agnostic plumbing (covered by gloo tests on CPU);
 ``NnueTrainer`` is GPU-only.
@@ -24,6 +27,8 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
+
+import os
 
 import torch
 import torch.distributed as dist
@@ -78,6 +83,9 @@ class DataParallel:
         self.enabled = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
+        # NNUE_DP_FORCE_COLLECTIVES=1 keeps the bucketed all-reduce path on even with one rank (rehearses the
+        # RCCL + hipGraph interplay on a single-GPU box; a 1-rank all-reduce is the identity)
+        self.collectives = self.enabled and (self.world > 1 or os.environ.get("NNUE_DP_FORCE_COLLECTIVES") == "1")
 
     @property
     def grad_scale(self) -> float:
@@ -94,7 +102,7 @@ class DataParallel:
             dist.broadcast(flat, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
 
     def allreduce_sum(self, flat: torch.Tensor, async_op: bool = False):
-        if self.world > 1:
+        if self.collectives:
             return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         return None
 
@@ -132,6 +140,9 @@ class NnueTrainer:
         self.dp.broadcast(self.flat_params)  # identical replicas even if ranks were seeded differently
         self.p = self.layout.views(self.flat_params)
         self.g = self.layout.views(self.flat_grads)
+        # gradient buckets: [threshold, conv weight] come last out of the backward and lead the flat buffer
+        assert self.layout.names[:2] == ["visual_threshold", "conv.weight"]
+        self.bucket_split = self.layout.offsets[2]
         for k, prm in model.named_parameters():
             if k not in SKIP:
                 prm.data = self.p[k]
@@ -166,7 +177,7 @@ class NnueTrainer:
         self.steps_done = 0
         self.use_graph = use_graph
         self._g_local, self._g_update = {}, None
-        self._plan_local = self._plan_update_first = self._plan_update = None
+        self._plan_local = self._plan_a = self._plan_b = self._plan_update_first = self._plan_update = None
         self._side = torch.cuda.Stream(device=self.dev) if use_graph else None
 
     # ------------------------------------------------------------------ kernel sequences
@@ -189,8 +200,8 @@ class NnueTrainer:
         lib.classifier_forward(self.ft, True, *self._cls_params(), self.clip, scratch=self.cls_scratch,
                                out=(self.h1, self.h2, self.logits))
 
-    def _local_step(self) -> None:
-        """forward + loss + backward into the flat gradient buffer (every element is overwritten)."""
+    def _local_a(self) -> None:
+        """features, classifier (forward + loss + backward), FT weight/bias gradient: fills the big bucket."""
         p, g = self.p, self.g
         self._features()
         cls_grads = tuple(g[f"classifier.classifier.{i}.{n}"] for i in (0, 2, 4) for n in ("weight", "bias"))
@@ -199,12 +210,23 @@ class NnueTrainer:
                                   grads=cls_grads, d_x=self.d_ft)
         if self.use_bits:
             lib.ftb_backward_weight(self.d_ft, self.bits, d_weight=g["input.weight"], d_bias=g["input.bias"])
-            lib.ftb_backward_values(self.d_ft, p["input.weight"], self.bits, dst=self.d_conv_out)
         else:
             lib.ft_backward_weight(self.d_ft, self.act, self.F, d_weight=g["input.weight"], d_bias=g["input.bias"])
+
+    def _local_b(self) -> None:
+        """FT value gradient -> d(conv_out) -> threshold and conv-weight gradients: fills the small bucket."""
+        p, g = self.p, self.g
+        if self.use_bits:
+            lib.ftb_backward_values(self.d_ft, p["input.weight"], self.bits, dst=self.d_conv_out)
+        else:
             lib.ft_backward_values(self.d_ft, p["input.weight"], self.act, self.P, dst=self.d_conv_out)
         lib.ste_conv_backward(self.images, self.conv_out, p["visual_threshold"], self.d_conv_out, self.stride,
                               d_thr=g["visual_threshold"], d_weight=g["conv.weight"], scratch=self.ste_scratch)
+
+    def _local_step(self) -> None:
+        """forward + loss + backward into the flat gradient buffer (every element is overwritten)."""
+        self._local_a()
+        self._local_b()
 
     def _update(self, first: bool) -> None:
         lib.sgd_step(self.flat_params, self.flat_grads, self.flat_momentum, self.lr, self.momentum, self.weight_decay,
@@ -214,7 +236,8 @@ class NnueTrainer:
         graph = torch.cuda.CUDAGraph()
         self._side.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self._side):
-            with torch.cuda.graph(graph, stream=self._side):
+            # thread_local: the collective's watchdog thread may query events while we capture
+            with torch.cuda.graph(graph, stream=self._side, capture_error_mode="thread_local"):
                 lib.run_plan(plan, torch.cuda.current_stream(self.dev).cuda_stream)
         torch.cuda.current_stream(self.dev).wait_stream(self._side)
         return graph
@@ -224,8 +247,12 @@ class NnueTrainer:
         recorded on throw-away copies of the buffers' contents, which are restored afterwards)."""
         if self._plan_local is None:
             with lib.record_calls() as calls:
-                self._local_step()
-            self._plan_local = list(calls)
+                self._local_a()
+            self._plan_a = list(calls)
+            with lib.record_calls() as calls:
+                self._local_b()
+            self._plan_b = list(calls)
+            self._plan_local = self._plan_a + self._plan_b
             keep = (self.flat_params.clone(), self.flat_grads.clone(),
                     None if self.flat_momentum is None else self.flat_momentum.clone(), self.grad_norm.clone())
             with lib.record_calls() as calls:
@@ -241,9 +268,9 @@ class NnueTrainer:
             self.grad_norm.copy_(keep[3])
         return self._plan_local, self._plan_update_first, self._plan_update
 
-    def _local_plan_for(self, slot: int):
-        """The recorded sequence with slot 0's input pointers swapped for `slot`'s."""
-        local = self._plan_local
+    def _local_plan_for(self, slot: int, part: str = "all"):
+        """The recorded sequence ("all", or its "a" / "b" half) with slot 0's input pointers swapped for `slot`'s."""
+        local = {"all": self._plan_local, "a": self._plan_a, "b": self._plan_b}[part]
         if slot == 0:
             return local
         swap = {self.inputs[0][0].data_ptr(): self.inputs[slot][0].data_ptr(),
@@ -271,18 +298,36 @@ class NnueTrainer:
         _, upd_first, upd = self._plans()
         first = self.steps_done == 0
         stream = torch.cuda.current_stream(self.dev).cuda_stream
-        if self.use_graph and timers is None:
-            if slot not in self._g_local:
-                self._g_local[slot] = self._capture(self._local_plan_for(slot))
+        graphs = self.use_graph and timers is None
+
+        parts = ("a", "b") if self.dp.collectives else ("all",)
+        if graphs:  # capture everything this step replays before any collective is enqueued
+            for part in parts:
+                if (slot, part) not in self._g_local:
+                    self._g_local[(slot, part)] = self._capture(self._local_plan_for(slot, part))
             if self._g_update is None:
                 self._g_update = self._capture(upd)
-            self._g_local[slot].replay()
+
+        def run(part):
+            if graphs:
+                self._g_local[(slot, part)].replay()
+            else:
+                lib.run_plan(self._local_plan_for(slot, part), stream, timers)
+
+        if not self.dp.collectives:
+            run("all")
         else:
-            lib.run_plan(self._local_plan_for(slot), stream, timers)
-        self.dp.allreduce_sum(self.flat_grads)
+            # big bucket is complete after part a: its all-reduce runs on the collective's own stream while part b
+            # (value gradient + STE/conv backward) still computes; the tail bucket follows part b
+            run("a")
+            big = self.dp.allreduce_sum(self.flat_grads[self.bucket_split:], async_op=True)
+            run("b")
+            small = self.dp.allreduce_sum(self.flat_grads[:self.bucket_split], async_op=True)
+            big.wait()
+            small.wait()
         if first:
             lib.run_plan(upd_first, stream, timers)
-        elif self.use_graph and timers is None:
+        elif graphs:
             self._g_update.replay()
         else:
             lib.run_plan(upd, stream, timers)
