@@ -176,11 +176,30 @@ def main():
     }
     kernels = {k: {"avg_us": round(dur_us[k], 2), **({"alg_GBps": round(alg[k] / dur_us[k] * 1e-3, 1)} if k in alg and dur_us[k] > 0 else {})}
                for k in names}
+    def pmc_traffic(entry):
+        """HBM-side bytes per launch of the kernel behind a C entry point, from the committed rocprofv3 --pmc passes
+        (profiles/*pmc_traffic.json, FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; separate passes, C2
+        workload).  Counters cannot be read inside this process, so other workloads report null."""
+        if args.workload != "c2":
+            return None
+        files = sorted((ROOT / "profiles").glob("*pmc_traffic.json"))
+        if not files:
+            return None
+        kernels = json.loads(files[-1].read_text())["kernels"]
+        want = {"nnue_ftb_forward": ("ftb_gather_kernel", ", 0,"), "nnue_ftb_backward_weight": ("ftb_gather_kernel", ", 1,"),
+                "nnue_ftb_backward_values": ("ftb_values_kernel", ""), "nnue_ft_forward": ("ft_forward_wide", ""),
+                "nnue_ft_backward_weight": ("ft_backward_weight_wide", ""), "nnue_ft_backward_values": ("ft_backward_values_wide", "")}.get(entry)
+        for name, v in kernels.items():
+            if want and name.startswith(want[0]) and want[1] in name:
+                return {"bytes": v["hbm_bytes_corrected"], "l2_hit_rate": v["l2_hit_rate"], "source": f"profiles/{files[-1].name}"}
+        return None
+
     dom = max(alg, key=lambda k: dur_us[k])
     achieved = alg[dom] / (dur_us[dom] * 1e-6) / 1e9 if dur_us[dom] > 0 else 0.0
     table_mb = model.input.weight.numel() * 4 / 1e6
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": (pmc_traffic(dom) or {}).get("bytes"),
+                "traffic_detail": pmc_traffic(dom),
                 "alg_bytes_per_launch": int(alg[dom]), "avg_launch_us": round(dur_us[dom], 2),
                 "regime": ("table %.1f MB is L2/Infinity-Cache resident: algorithmic rate is cache bandwidth and may exceed the HBM peak"
                            % table_mb) if table_mb < 200 else "table %.0f MB exceeds the Infinity Cache: HBM-bound" % table_mb}
