@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 4
+#define NNUE_HIP_ABI_VERSION 5
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -147,10 +147,13 @@ int nnue_ftb_list_tiles(int B, int F, int P, int* tiles_fwd, int* tiles_bwd);
 int64_t nnue_ftb_scratch(int B, int F, int P, int L1); /* bytes for nnue_ftb_forward / _backward_weight */
 
 /* StraightThroughBinary.forward + _to_sparse_features as bit masks and tile lists (nnue.py:19-25,
- * :590-635).  Also writes n[b] = number of active positions.  Bit-exact given conv_out. */
+ * :590-635).  Also writes n[b] = number of active positions.  Bit-exact given conv_out.
+ * stages: 1 = per-sample outputs (maskW, sink, n, tlW/tcW), 2 = transposed outputs (maskT, tlT/tcT; needs
+ * sink from stage 1), 3 = both.  The transposed outputs are only read by nnue_ftb_backward_weight, so a
+ * caller may run stage 2 on a second stream beside the forward. */
 int nnue_binarize_bits(const float* conv_out, const float* thr, int B, int fps, int Gh, int Gw, int F,
                        uint64_t* maskW, int pw64, uint64_t* maskT, int bw64, float* sink, int32_t* n,
-                       uint8_t* tlW, uint8_t* tcW, uint8_t* tlT, uint8_t* tcT, nnue_stream_t stream);
+                       uint8_t* tlW, uint8_t* tcW, uint8_t* tlT, uint8_t* tcT, int stages, nnue_stream_t stream);
 
 /* FeatureTransformer.forward for binary features (nnue.py:686-710):
  *   out[b,:] = bias + sum_{p active, p < min(F-1,P)} weight[p,:] + sink[b] * weight[F-1,:] */
@@ -198,6 +201,9 @@ int nnue_classifier_backward(const float* x, int pairwise,
  * (nnue.py:660-669, :728-734 + compute_loss, train.py:250-254, and their autograd): same results as
  * nnue_classifier_forward -> nnue_cross_entropy(grad_scale) -> nnue_classifier_backward, but the narrow
  * layers, the loss and their backward run per sample in a single kernel.  d_x may be NULL.
+ * phases: 1 = activations, per-sample losses and d_x (the critical path of a training step), 2 = the mean loss
+ * and the six weight/bias gradients (needs phase 1 on the same scratch; nothing downstream waits for it, so a
+ * caller may run it on a second stream), 3 = both.
  * scratch >= nnue_classifier_train_scratch(B, L1, L2, L3, C) bytes. */
 int64_t nnue_classifier_train_scratch(int B, int L1, int L2, int L3, int C);
 int nnue_classifier_train_step(const float* x, int pairwise,
@@ -208,7 +214,7 @@ int nnue_classifier_train_step(const float* x, int pairwise,
                                float* h1, float* h2, float* logits, float* sample_loss, float* loss,
                                float* d_x, float* d_w1, float* d_b1, float* d_w2, float* d_b2,
                                float* d_w3, float* d_b3,
-                               void* scratch, int64_t scratch_bytes, nnue_stream_t stream);
+                               void* scratch, int64_t scratch_bytes, int phases, nnue_stream_t stream);
 
 /* ---- loss + step tail ---------------------------------------------------------- */
 

@@ -415,7 +415,9 @@ __global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restric
                                                           const float* __restrict__ h1, const float* __restrict__ h2,
                                                           int B, int L2, int L3, int C, float* __restrict__ d_w3,
                                                           float* __restrict__ d_b3, float* __restrict__ d_w2,
-                                                          float* __restrict__ d_b2, float* __restrict__ d_b1) {
+                                                          float* __restrict__ d_b2, float* __restrict__ d_b1,
+                                                          const float* __restrict__ sample_loss,
+                                                          float* __restrict__ loss_out) {
   long long o = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int v3 = (L3 % 4 == 0) ? 4 : 1, v2 = (L2 % 4 == 0) ? 4 : 1;
@@ -436,6 +438,12 @@ __global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restric
     pa = d_z2 + o; sa = L3; dst = d_b2 + o;
   } else if ((o -= L3) < L2) {
     pa = d_z1 + o; sa = L2; dst = d_b1 + o;
+  } else if (o == L2 && loss_out != nullptr) {  // one more wave: mean of the per-sample losses, fixed order
+    float acc = 0.f;
+    for (int b = lane; b < B; b += 64) acc += sample_loss[b];
+    acc = wave_sum(acc);
+    if (lane == 0) *loss_out = acc / (float)B;
+    return;
   } else {
     return;
   }
@@ -571,16 +579,6 @@ __global__ __launch_bounds__(128) void tail_train_kernel(const float* __restrict
   }
 }
 
-__global__ __launch_bounds__(256) void loss_mean_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
-  __shared__ float red[4];
-  float acc = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) acc += v[i];
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) *out = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
-}
-
 // ------------------------------------------------------------------ shape policy (shared by scratch + launch)
 struct ClsPlan {
   bool fwd_mfma, bww_mfma, bwx_mfma;
@@ -685,7 +683,7 @@ extern "C" int nnue_classifier_backward(const float* x, int pairwise, const floa
   {
     const long long outs = (long long)C * (L3 % 4 == 0 ? L3 / 4 : L3) + (long long)L3 * (L2 % 4 == 0 ? L2 / 4 : L2) + C + L3 + L2;
     hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, s, d_logits, d_z2, d_z1, h1, h2, B,
-                       L2, L3, C, d_w3, d_b3, d_w2, d_b2, d_b1);
+                       L2, L3, C, d_w3, d_b3, d_w2, d_b2, d_b1, (const float*)nullptr, (float*)nullptr);
   }
   if (p.bww_mfma) {
     const long long waves = (long long)(L2 / 32) * (L1 / 64) * p.bww_ksplit;
@@ -745,9 +743,10 @@ extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const fl
                                           const int64_t* labels, float grad_scale, int B, int L1, int L2, int L3, int C,
                                           float* h1, float* h2, float* logits, float* sample_loss, float* loss, float* d_x,
                                           float* d_w1, float* d_b1, float* d_w2, float* d_b2, float* d_w3, float* d_b3,
-                                          void* scratch, int64_t scratch_bytes, nnue_stream_t stream) {
+                                          void* scratch, int64_t scratch_bytes, int phases, nnue_stream_t stream) {
   NNUE_REQUIRE(x && w1 && b1 && w2 && b2 && w3 && b3 && labels && h1 && h2 && logits && sample_loss && loss && scratch,
                NNUE_E_ARG, "nnue_classifier_train_step: null pointer");
+  NNUE_REQUIRE(phases >= 1 && phases <= 3, NNUE_E_ARG, "nnue_classifier_train_step: phases must be 1 (activations + d_x), 2 (weight gradients + loss) or 3 (both)");
   NNUE_REQUIRE(d_w1 && d_b1 && d_w2 && d_b2 && d_w3 && d_b3, NNUE_E_ARG, "nnue_classifier_train_step: null gradient pointer");
   NNUE_REQUIRE(B > 0 && L1 > 0 && L2 > 0 && L3 > 0 && C > 0, NNUE_E_ARG,
                "nnue_classifier_train_step: B=%d L1=%d L2=%d L3=%d C=%d must be positive", B, L1, L2, L3, C);
@@ -764,40 +763,41 @@ extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const fl
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* base = static_cast<float*>(scratch);
   float *part = base + t.part, *d_z1 = base + t.d_z1, *d_z2 = base + t.d_z2, *d_logits = base + t.d_logits, *slabs = base + t.slabs;
-  if (p.fwd_mfma) {
-    const long long waves = (long long)((B + 15) / 16) * ((L2 + 63) / 64) * p.fwd_ksplit;
-    hipLaunchKernelGGL(l1_forward_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, B, L1, L2, p.fwd_ksplit, part);
-  } else {
-    const long long waves = (long long)B * L2;
-    hipLaunchKernelGGL(l1_forward_simple, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, B, L1, L2, part);
-  }
-  hipLaunchKernelGGL(tail_train_kernel, dim3(B), dim3(128), (size_t)tail_lds, s, part, p.fwd_ksplit, b1, w2, b2, w3, b3, clip, labels,
-                     grad_scale / (float)B, B, L2, L3, C, h1, h2, logits, sample_loss, d_logits, d_z1, d_z2);
-  hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(256), 0, s, sample_loss, B, loss);
-  {
-    const long long outs = (long long)C * (L3 % 4 == 0 ? L3 / 4 : L3) + (long long)L3 * (L2 % 4 == 0 ? L2 / 4 : L2) + C + L3 + L2;
-    hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, s, d_logits, d_z2, d_z1, h1, h2, B, L2, L3, C,
-                       d_w3, d_b3, d_w2, d_b2, d_b1);
-  }
-  if (p.bww_mfma) {
-    const long long waves = (long long)(L2 / 32) * (L1 / 64) * p.bww_ksplit;
-    float* target = p.bww_ksplit > 1 ? slabs : d_w1;
-    hipLaunchKernelGGL(l1_backward_w_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, d_z1, B, L1, L2, p.bww_ksplit,
-                       p.bww_klen, target);
-    if (p.bww_ksplit > 1) {
-      const long long count = (long long)L2 * L1;
-      hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, s, slabs, p.bww_ksplit, count, d_w1);
-    }
-  } else {
-    hipLaunchKernelGGL(l1_backward_w_simple, dim3(L2, (L1 + 255) / 256), dim3(256), 0, s, x, pairwise, d_z1, B, L1, L2, d_w1);
-  }
-  if (d_x) {
-    if (p.bwx_mfma) {
-      const long long waves = (long long)((B + 15) / 16) * (L1 / 32);
-      hipLaunchKernelGGL(l1_backward_x_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1, L2, d_x);
+  if (phases & 1) {
+    if (p.fwd_mfma) {
+      const long long waves = (long long)((B + 15) / 16) * ((L2 + 63) / 64) * p.fwd_ksplit;
+      hipLaunchKernelGGL(l1_forward_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, B, L1, L2, p.fwd_ksplit, part);
     } else {
-      const int cols = pairwise ? L1 / 2 : L1;
-      hipLaunchKernelGGL(l1_backward_x_simple, dim3(B, (cols + 255) / 256), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1, L2, d_x);
+      const long long waves = (long long)B * L2;
+      hipLaunchKernelGGL(l1_forward_simple, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, B, L1, L2, part);
+    }
+    hipLaunchKernelGGL(tail_train_kernel, dim3(B), dim3(128), (size_t)tail_lds, s, part, p.fwd_ksplit, b1, w2, b2, w3, b3, clip, labels,
+                       grad_scale / (float)B, B, L2, L3, C, h1, h2, logits, sample_loss, d_logits, d_z1, d_z2);
+    if (d_x) {
+      if (p.bwx_mfma) {
+        const long long waves = (long long)((B + 15) / 16) * (L1 / 32);
+        hipLaunchKernelGGL(l1_backward_x_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1, L2, d_x);
+      } else {
+        const int cols = pairwise ? L1 / 2 : L1;
+        hipLaunchKernelGGL(l1_backward_x_simple, dim3(B, (cols + 255) / 256), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1, L2, d_x);
+      }
+    }
+  }
+  if (phases & 2) {  // needs phase 1's h1, h2, d_logits, d_z1, d_z2 (scratch) -- nothing downstream depends on it
+    const long long outs = (long long)C * (L3 % 4 == 0 ? L3 / 4 : L3) + (long long)L3 * (L2 % 4 == 0 ? L2 / 4 : L2) + C + L3 + L2 + 1;
+    hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, s, d_logits, d_z2, d_z1, h1, h2, B, L2, L3, C,
+                       d_w3, d_b3, d_w2, d_b2, d_b1, (const float*)sample_loss, loss);
+    if (p.bww_mfma) {
+      const long long waves = (long long)(L2 / 32) * (L1 / 64) * p.bww_ksplit;
+      float* target = p.bww_ksplit > 1 ? slabs : d_w1;
+      hipLaunchKernelGGL(l1_backward_w_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, d_z1, B, L1, L2, p.bww_ksplit,
+                         p.bww_klen, target);
+      if (p.bww_ksplit > 1) {
+        const long long count = (long long)L2 * L1;
+        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, s, slabs, p.bww_ksplit, count, d_w1);
+      }
+    } else {
+      hipLaunchKernelGGL(l1_backward_w_simple, dim3(L2, (L1 + 255) / 256), dim3(256), 0, s, x, pairwise, d_z1, B, L1, L2, d_w1);
     }
   }
   return nnue_launch_status("nnue_classifier_train_step");

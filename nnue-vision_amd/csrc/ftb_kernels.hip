@@ -571,7 +571,7 @@ extern "C" int64_t nnue_ftb_scratch(int B, int F, int P, int L1) {
 
 extern "C" int nnue_binarize_bits(const float* conv_out, const float* thr, int B, int fps, int Gh, int Gw, int F,
                                   uint64_t* maskW, int pw64, uint64_t* maskT, int bw64, float* sink, int32_t* n,
-                                  uint8_t* tlW, uint8_t* tcW, uint8_t* tlT, uint8_t* tcT, nnue_stream_t stream) {
+                                  uint8_t* tlW, uint8_t* tcW, uint8_t* tlT, uint8_t* tcT, int stages, nnue_stream_t stream) {
   NNUE_REQUIRE(conv_out && thr && maskW && maskT && sink && n && tlW && tcW && tlT && tcT, NNUE_E_ARG,
                "nnue_binarize_bits: null pointer");
   NNUE_REQUIRE(B > 0 && fps > 0 && Gh > 0 && Gw > 0 && F > 0, NNUE_E_ARG,
@@ -587,9 +587,12 @@ extern "C" int nnue_binarize_bits(const float* conv_out, const float* thr, int B
   int ntf = 0, ntb = 0;
   nnue_ftb_list_tiles(B, F, P, &ntf, &ntb);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(bits_rows_kernel, dim3(B), dim3(256), 0, s, conv_out, thr, Gh * Gw, P, F, reinterpret_cast<u64*>(maskW), pw64,
-                     sink, n, reinterpret_cast<unsigned short*>(tlW), tcW, ntf);
-  hipLaunchKernelGGL(bits_transpose_kernel, dim3((F + 1 + kTrRows - 1) / kTrRows, ntb), dim3(256), 0, s, conv_out, thr, sink, B, Gh * Gw, P, F,
+  NNUE_REQUIRE(stages >= 1 && stages <= 3, NNUE_E_ARG, "nnue_binarize_bits: stages must be 1 (per-sample), 2 (transposed) or 3 (both)");
+  if (stages & 1)
+    hipLaunchKernelGGL(bits_rows_kernel, dim3(B), dim3(256), 0, s, conv_out, thr, Gh * Gw, P, F, reinterpret_cast<u64*>(maskW), pw64,
+                       sink, n, reinterpret_cast<unsigned short*>(tlW), tcW, ntf);
+  if (stages & 2)
+    hipLaunchKernelGGL(bits_transpose_kernel, dim3((F + 1 + kTrRows - 1) / kTrRows, ntb), dim3(256), 0, s, conv_out, thr, sink, B, Gh * Gw, P, F,
                      reinterpret_cast<u64*>(maskT), bw64, reinterpret_cast<unsigned short*>(tlT), tcT, ntb);
   return nnue_launch_status("nnue_binarize_bits");
 }

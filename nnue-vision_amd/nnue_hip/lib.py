@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -40,7 +40,7 @@ SIGNATURES = {
     "nnue_ftb_list_tiles": (_c_int, [_c_int, _c_int, _c_int, _c_p, _c_p]),
     "nnue_ftb_scratch": (_c_i64, [_c_int, _c_int, _c_int, _c_int]),
     "nnue_binarize_bits": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_int, _c_p, _c_int,
-                                    _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
+                                    _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_p]),
     "nnue_ftb_forward": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_i64, _c_p]),
     "nnue_ftb_backward_weight": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p,
                                           _c_p, _c_i64, _c_p]),
@@ -56,7 +56,7 @@ SIGNATURES = {
     "nnue_classifier_train_step": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_f, _c_p, _c_f,
                                             _c_int, _c_int, _c_int, _c_int, _c_int,
                                             _c_p, _c_p, _c_p, _c_p, _c_p,
-                                            _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
+                                            _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
     "nnue_cross_entropy": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_f, _c_p, _c_p, _c_p, _c_p]),
     "nnue_sgd_scratch": (_c_i64, [_c_i64]),
     "nnue_sgd_step": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_int,
@@ -375,7 +375,7 @@ def use_bit_path(num_rows: int, l1: int) -> bool:
 
 
 def binarize_bits(conv_out: torch.Tensor, thr: torch.Tensor, num_rows: int, l1: int,
-                  bits: Optional[FeatureBits] = None) -> FeatureBits:
+                  bits: Optional[FeatureBits] = None, stages: int = 3) -> FeatureBits:
     conv_out = _need(conv_out, torch.float32, "conv_out")
     if conv_out.dim() != 4:
         raise ValueError(f"conv_out: expected [B,fps,Gh,Gw], got {tuple(conv_out.shape)}")
@@ -387,7 +387,7 @@ def binarize_bits(conv_out: torch.Tensor, thr: torch.Tensor, num_rows: int, l1: 
         raise ValueError("binarize_bits: bit buffers do not match the map")
     _call("nnue_binarize_bits", conv_out.data_ptr(), thr.data_ptr(), b, fps, gh, gw, num_rows, bits.maskW.data_ptr(),
           bits.maskW.shape[1], bits.maskT.data_ptr(), bits.maskT.shape[1], bits.sink.data_ptr(), bits.n.data_ptr(),
-          bits.tlW.data_ptr(), bits.tcW.data_ptr(), bits.tlT.data_ptr(), bits.tcT.data_ptr(), _stream(conv_out))
+          bits.tlW.data_ptr(), bits.tcW.data_ptr(), bits.tlT.data_ptr(), bits.tcT.data_ptr(), int(stages), _stream(conv_out))
     return bits
 
 
@@ -502,7 +502,7 @@ def classifier_train_scratch_bytes(b: int, l1: int, l2: int, l3: int, c: int) ->
 
 def classifier_train_step(x, pairwise: bool, w1, b1, w2, b2, w3, b3, labels, grad_scale: float = 1.0, clip: float = 0.0,
                           want_dx: bool = True, scratch: Optional[torch.Tensor] = None, out=None, loss_out=None,
-                          grads=None, d_x=None):
+                          grads=None, d_x=None, phases: int = 3):
     """Forward + mean cross-entropy + backward of the classifier block in one C call.
     Returns (h1, h2, logits), (sample_loss, loss), d_x, grads."""
     x = _need(x, torch.float32, "classifier input")
@@ -528,7 +528,8 @@ def classifier_train_step(x, pairwise: bool, w1, b1, w2, b2, w3, b3, labels, gra
     _call("nnue_classifier_train_step", x.data_ptr(), int(bool(pairwise)), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
           b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), float(clip), labels.data_ptr(), float(grad_scale), b, l1, l2, l3, c,
           h1.data_ptr(), h2.data_ptr(), logits.data_ptr(), sample_loss.data_ptr(), loss.data_ptr(),
-          _ptr(d_x if want_dx else None), *[g.data_ptr() for g in grads], scratch.data_ptr(), scratch.numel(), _stream(x))
+          _ptr(d_x if want_dx else None), *[g.data_ptr() for g in grads], scratch.data_ptr(), scratch.numel(), int(phases),
+          _stream(x))
     return (h1, h2, logits), (sample_loss, loss), (d_x if want_dx else None), grads
 
 

@@ -177,82 +177,138 @@ class NnueTrainer:
         self.steps_done = 0
         self.use_graph = use_graph
         self._g_local, self._g_update = {}, None
-        self._plan_local = self._plan_a = self._plan_b = self._plan_update_first = self._plan_update = None
+        self._plan_local = self._plan_seg = self._plan_update_first = self._plan_update = None
         self._side = torch.cuda.Stream(device=self.dev) if use_graph else None
+        self._s1 = torch.cuda.Stream(device=self.dev) if use_graph else None
+        self._s2 = torch.cuda.Stream(device=self.dev) if use_graph else None
+        # NNUE_GRAPH_BRANCHES=1 captures the off-critical-path segments on side streams.  Measured on MI355X /
+        # ROCm 7.0 (C2): 0.230 ms/step forked vs 0.175 ms/step as one chain -- the graph's fork/join edges cost
+        # more than the overlap returns, so the default is the linear chain.
+        self.branch = os.environ.get("NNUE_GRAPH_BRANCHES", "0") == "1"
 
     # ------------------------------------------------------------------ kernel sequences
     def _cls_params(self):
         p = self.p
         return [p[f"classifier.classifier.{i}.{n}"] for i in (0, 2, 4) for n in ("weight", "bias")]
 
-    def _features(self) -> None:
-        p = self.p
-        lib.conv3x3_forward(self.images, p["conv.weight"], self.stride, out=self.conv_out)
-        if self.use_bits:
-            lib.binarize_bits(self.conv_out, p["visual_threshold"], self.F, self.L1, bits=self.bits)
-            lib.ftb_forward(p["input.weight"], p["input.bias"], self.bits, out=self.ft)
-        else:
-            lib.binarize_features(self.conv_out, p["visual_threshold"], self.F, act=self.act)
-            lib.ft_forward(p["input.weight"], p["input.bias"], self.act, out=self.ft)
+    # The step is cut into segments so that a captured graph can run the ones nothing waits for beside the
+    # critical path (conv -> bits -> FT forward -> classifier activations/d_x -> value gradient -> STE):
+    #   front      conv, per-sample bit masks + forward tile lists                       main
+    #   transpose  transposed masks + backward tile lists (only the FT weight gradient reads them)   side 1
+    #   forward    FT forward, classifier phase 1 (activations, loss per sample, d_ft)  main
+    #   ft_wgrad   FT weight/bias gradient                                              side 1
+    #   cls_wgrad  classifier weight/bias gradients + mean loss                         side 2
+    #   tail       FT value gradient -> d(conv_out) -> threshold / conv-weight gradients main  (bucket "b")
+    SEGMENTS = ("front", "transpose", "forward", "ft_wgrad", "cls_wgrad", "tail")
 
-    def _forward(self) -> None:
-        self._features()
-        lib.classifier_forward(self.ft, True, *self._cls_params(), self.clip, scratch=self.cls_scratch,
-                               out=(self.h1, self.h2, self.logits))
-
-    def _local_a(self) -> None:
-        """features, classifier (forward + loss + backward), FT weight/bias gradient: fills the big bucket."""
-        p, g = self.p, self.g
-        self._features()
+    def _cls_step(self, phases: int) -> None:
+        g = self.g
         cls_grads = tuple(g[f"classifier.classifier.{i}.{n}"] for i in (0, 2, 4) for n in ("weight", "bias"))
         lib.classifier_train_step(self.ft, True, *self._cls_params(), self.labels, 1.0, self.clip, scratch=self.cls_scratch,
                                   out=(self.h1, self.h2, self.logits), loss_out=(self.sample_loss, self.loss),
-                                  grads=cls_grads, d_x=self.d_ft)
-        if self.use_bits:
-            lib.ftb_backward_weight(self.d_ft, self.bits, d_weight=g["input.weight"], d_bias=g["input.bias"])
-        else:
-            lib.ft_backward_weight(self.d_ft, self.act, self.F, d_weight=g["input.weight"], d_bias=g["input.bias"])
+                                  grads=cls_grads, d_x=self.d_ft, phases=phases)
 
-    def _local_b(self) -> None:
-        """FT value gradient -> d(conv_out) -> threshold and conv-weight gradients: fills the small bucket."""
+    def _segment(self, name: str) -> None:
         p, g = self.p, self.g
-        if self.use_bits:
-            lib.ftb_backward_values(self.d_ft, p["input.weight"], self.bits, dst=self.d_conv_out)
+        if name == "front":
+            lib.conv3x3_forward(self.images, p["conv.weight"], self.stride, out=self.conv_out)
+            if self.use_bits:
+                lib.binarize_bits(self.conv_out, p["visual_threshold"], self.F, self.L1, bits=self.bits, stages=1)
+            else:
+                lib.binarize_features(self.conv_out, p["visual_threshold"], self.F, act=self.act)
+        elif name == "transpose":
+            if self.use_bits:
+                lib.binarize_bits(self.conv_out, p["visual_threshold"], self.F, self.L1, bits=self.bits, stages=2)
+        elif name == "forward":
+            if self.use_bits:
+                lib.ftb_forward(p["input.weight"], p["input.bias"], self.bits, out=self.ft)
+            else:
+                lib.ft_forward(p["input.weight"], p["input.bias"], self.act, out=self.ft)
+            self._cls_step(1)
+        elif name == "ft_wgrad":
+            if self.use_bits:
+                lib.ftb_backward_weight(self.d_ft, self.bits, d_weight=g["input.weight"], d_bias=g["input.bias"])
+            else:
+                lib.ft_backward_weight(self.d_ft, self.act, self.F, d_weight=g["input.weight"], d_bias=g["input.bias"])
+        elif name == "cls_wgrad":
+            self._cls_step(2)
+        elif name == "tail":
+            if self.use_bits:
+                lib.ftb_backward_values(self.d_ft, p["input.weight"], self.bits, dst=self.d_conv_out)
+            else:
+                lib.ft_backward_values(self.d_ft, p["input.weight"], self.act, self.P, dst=self.d_conv_out)
+            lib.ste_conv_backward(self.images, self.conv_out, p["visual_threshold"], self.d_conv_out, self.stride,
+                                  d_thr=g["visual_threshold"], d_weight=g["conv.weight"], scratch=self.ste_scratch)
         else:
-            lib.ft_backward_values(self.d_ft, p["input.weight"], self.act, self.P, dst=self.d_conv_out)
-        lib.ste_conv_backward(self.images, self.conv_out, p["visual_threshold"], self.d_conv_out, self.stride,
-                              d_thr=g["visual_threshold"], d_weight=g["conv.weight"], scratch=self.ste_scratch)
+            raise KeyError(name)
+
+    def _forward(self) -> None:
+        for name in ("front", "forward"):
+            self._segment(name)
 
     def _local_step(self) -> None:
         """forward + loss + backward into the flat gradient buffer (every element is overwritten)."""
-        self._local_a()
-        self._local_b()
+        for name in self.SEGMENTS:
+            self._segment(name)
 
     def _update(self, first: bool) -> None:
         lib.sgd_step(self.flat_params, self.flat_grads, self.flat_momentum, self.lr, self.momentum, self.weight_decay,
                      self.max_grad_norm, self.dp.grad_scale, first, self.grad_norm, self.sgd_scratch)
 
-    def _capture(self, plan) -> torch.cuda.CUDAGraph:
+    def _capture(self, fn) -> torch.cuda.CUDAGraph:
+        """Captures fn(main_stream) into a graph; fn may fork work onto self._s1 / self._s2 with events."""
         graph = torch.cuda.CUDAGraph()
         self._side.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self._side):
             # thread_local: the collective's watchdog thread may query events while we capture
             with torch.cuda.graph(graph, stream=self._side, capture_error_mode="thread_local"):
-                lib.run_plan(plan, torch.cuda.current_stream(self.dev).cuda_stream)
+                fn(torch.cuda.current_stream(self.dev))
         torch.cuda.current_stream(self.dev).wait_stream(self._side)
         return graph
+
+    def _run_local(self, slot: int, part: str, main: torch.cuda.Stream, branch: bool, timers=None) -> None:
+        """Launches the local segments of `part` ("all" | "a" | "b").  With `branch` (graph capture) the transposed
+        lists, the FT weight gradient and the classifier weight gradients go to side streams and are joined at
+        the end; otherwise everything is issued in order on `main`."""
+        seg = lambda name: self._seg_plan(slot, name)  # noqa: E731
+        m = main.cuda_stream
+        if part == "b":
+            lib.run_plan(seg("tail"), m, timers)
+            return
+        if not branch:
+            for name in ("front", "transpose", "forward", "ft_wgrad", "cls_wgrad"):
+                lib.run_plan(seg(name), m, timers)
+            if part == "all":
+                lib.run_plan(seg("tail"), m, timers)
+            return
+        s1, s2 = self._s1, self._s2
+        lib.run_plan(seg("front"), m)
+        e0 = torch.cuda.Event()
+        e0.record(main)
+        s1.wait_event(e0)
+        lib.run_plan(seg("transpose"), s1.cuda_stream)
+        lib.run_plan(seg("forward"), m)
+        e1 = torch.cuda.Event()
+        e1.record(main)
+        s1.wait_event(e1)
+        lib.run_plan(seg("ft_wgrad"), s1.cuda_stream)
+        s2.wait_event(e1)
+        lib.run_plan(seg("cls_wgrad"), s2.cuda_stream)
+        if part == "all":
+            lib.run_plan(seg("tail"), m)
+        main.wait_stream(s1)
+        main.wait_stream(s2)
 
     def _plans(self):
         """Records the three fixed call sequences once (this also executes them once; the update plans are
         recorded on throw-away copies of the buffers' contents, which are restored afterwards)."""
         if self._plan_local is None:
-            with lib.record_calls() as calls:
-                self._local_a()
-            self._plan_a = list(calls)
-            with lib.record_calls() as calls:
-                self._local_b()
-            self._plan_b = list(calls)
-            self._plan_local = self._plan_a + self._plan_b
+            self._plan_seg = {}
+            for name in self.SEGMENTS:
+                with lib.record_calls() as calls:
+                    self._segment(name)
+                self._plan_seg[name] = list(calls)
+            self._plan_local = [c for name in self.SEGMENTS for c in self._plan_seg[name]]
             keep = (self.flat_params.clone(), self.flat_grads.clone(),
                     None if self.flat_momentum is None else self.flat_momentum.clone(), self.grad_norm.clone())
             with lib.record_calls() as calls:
@@ -268,14 +324,14 @@ class NnueTrainer:
             self.grad_norm.copy_(keep[3])
         return self._plan_local, self._plan_update_first, self._plan_update
 
-    def _local_plan_for(self, slot: int, part: str = "all"):
-        """The recorded sequence ("all", or its "a" / "b" half) with slot 0's input pointers swapped for `slot`'s."""
-        local = {"all": self._plan_local, "a": self._plan_a, "b": self._plan_b}[part]
+    def _seg_plan(self, slot: int, name: str):
+        """The recorded calls of one segment with slot 0's input pointers swapped for `slot`'s."""
+        plan = self._plan_seg[name]
         if slot == 0:
-            return local
+            return plan
         swap = {self.inputs[0][0].data_ptr(): self.inputs[slot][0].data_ptr(),
                 self.inputs[0][1].data_ptr(): self.inputs[slot][1].data_ptr()}
-        return [(name, fn, tuple(swap.get(a, a) if isinstance(a, int) else a for a in args)) for name, fn, args in local]
+        return [(nm, fn, tuple(swap.get(a, a) if isinstance(a, int) else a for a in args)) for nm, fn, args in plan]
 
     # ------------------------------------------------------------------ public
     def step(self, images: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None, slot: int = 0,
@@ -301,18 +357,20 @@ class NnueTrainer:
         graphs = self.use_graph and timers is None
 
         parts = ("a", "b") if self.dp.collectives else ("all",)
+        main = torch.cuda.current_stream(self.dev)
         if graphs:  # capture everything this step replays before any collective is enqueued
             for part in parts:
                 if (slot, part) not in self._g_local:
-                    self._g_local[(slot, part)] = self._capture(self._local_plan_for(slot, part))
+                    self._g_local[(slot, part)] = self._capture(
+                        lambda st, part=part: self._run_local(slot, part, st, branch=self.branch))
             if self._g_update is None:
-                self._g_update = self._capture(upd)
+                self._g_update = self._capture(lambda st: lib.run_plan(upd, st.cuda_stream))
 
         def run(part):
             if graphs:
                 self._g_local[(slot, part)].replay()
             else:
-                lib.run_plan(self._local_plan_for(slot, part), stream, timers)
+                self._run_local(slot, part, main, branch=False, timers=timers)
 
         if not self.dp.collectives:
             run("all")
