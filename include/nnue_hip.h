@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 5
+#define NNUE_HIP_ABI_VERSION 6
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -225,6 +225,13 @@ int nnue_classifier_train_step(const float* x, int pairwise,
  * row -- the caller validates labels; the kernel only stays in bounds. */
 int nnue_cross_entropy(const float* logits, const int64_t* labels, int B, int C, float grad_scale,
                        float* sample_loss, float* loss, float* d_logits, nnue_stream_t stream);
+
+/* Prediction bookkeeping of compute_metrics / evaluate_model (evaluate.py:23-59, :62-87): adds this batch to
+ * confusion[truth*K + pred] (uint64, K = C, or 2 when C == 1).  pred = first arg-max of the row (numpy's
+ * rule); C == 1 uses the reference's binary rule (output > 0.5, target > 0.5).  Accumulates: zero the matrix
+ * once before the first batch.  Integer atomics: the result does not depend on execution order. */
+int nnue_confusion_accumulate(const float* logits, const int64_t* labels, int B, int C,
+                              uint64_t* confusion, nnue_stream_t stream);
 
 /* clip_grad_norm_ + SGD(momentum, weight_decay) on flat buffers (train.py:363-366, :457-464):
  *   g <- g * grad_scale              (1/world after a summed all-reduce)

@@ -55,6 +55,33 @@ __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ v, 
   if (threadIdx.x == 0) *out = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
 }
 
+// evaluation: argmax (first maximum, as numpy) and one integer atomic per sample into the confusion matrix;
+// C == 1 is the reference's binary rule (output > 0.5 vs target > 0.5)
+__global__ __launch_bounds__(256) void confusion_kernel(const float* __restrict__ logits,
+                                                        const int64_t* __restrict__ labels, int B, int C, int K,
+                                                        unsigned long long* __restrict__ confusion) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const float* __restrict__ z = logits + (size_t)b * C;
+  int pred, truth;
+  if (C == 1) {
+    pred = z[0] > 0.5f ? 1 : 0;
+    truth = labels[b] > 0 ? 1 : 0;  // integer labels: > 0.5  <=>  >= 1
+  } else {
+    pred = 0;
+    float best = z[0];
+    for (int c = 1; c < C; ++c)
+      if (z[c] > best) {
+        best = z[c];
+        pred = c;
+      }
+    const int64_t y = labels[b];
+    if (y < 0 || y >= K) return;  // out-of-range label: not counted (caller validates)
+    truth = (int)y;
+  }
+  atomicAdd(&confusion[(size_t)truth * K + pred], 1ull);
+}
+
 constexpr int kNormBlocks = 512;
 
 __global__ __launch_bounds__(256) void sqnorm_stage1(const float* __restrict__ g, int64_t count, float scale,
@@ -145,4 +172,14 @@ extern "C" int nnue_sgd_step(float* params, float* grads, float* momentum_buf, i
   hipLaunchKernelGGL(sgd_apply_kernel, dim3(blocks), dim3(256), 0, s, params, grads, momentum == 0.0f ? nullptr : momentum_buf,
                      count, lr, momentum, weight_decay, max_norm, grad_scale, first_step, partial, kNormBlocks, norm_out);
   return nnue_launch_status("nnue_sgd_step");
+}
+
+extern "C" int nnue_confusion_accumulate(const float* logits, const int64_t* labels, int B, int C, uint64_t* confusion,
+                                         nnue_stream_t stream) {
+  NNUE_REQUIRE(logits && labels && confusion, NNUE_E_ARG, "nnue_confusion_accumulate: null pointer");
+  NNUE_REQUIRE(B > 0 && C > 0, NNUE_E_ARG, "nnue_confusion_accumulate: B=%d C=%d must be positive", B, C);
+  const int K = C == 1 ? 2 : C;
+  hipLaunchKernelGGL(confusion_kernel, dim3((B + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), logits, labels, B, C, K,
+                     reinterpret_cast<unsigned long long*>(confusion));
+  return nnue_launch_status("nnue_confusion_accumulate");
 }

@@ -1,0 +1,90 @@
+"""Drop-in for the PyTorch half of the reference's ``evaluate.py``: ``compute_metrics`` and
+``evaluate_model`` (evaluate.py:23-59, :62-87), which ``train.py:378-398`` runs over the whole train AND
+validation set after every epoch.
+
+The reference moves every batch's logits to the host and calls four sklearn scorers on the concatenation.
+Here a batch costs one forward pass, one cross-entropy kernel and one confusion-matrix kernel (integer
+atomics) on the GPU; the per-batch mean losses and the K x K matrix stay on the device and are read back
+once.  Accuracy and the support-weighted precision / recall / F1 (``zero_division=0``) are then formed from
+the matrix in float64 -- the same numbers sklearn produces, without sklearn.
+
+``evaluate_compiled_model`` (one subprocess of the C++ engine per image) is out of scope and stays with the
+reference.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from nnue_hip import lib as _lib
+
+
+def metrics_from_confusion(confusion) -> Dict[str, float]:
+    """confusion[truth, pred] (any integer array-like) -> {"acc", "f1", "precision", "recall"} as sklearn's
+    accuracy_score and the average="weighted", zero_division=0 scorers compute them."""
+    m = np.asarray(confusion, dtype=np.float64)
+    total = m.sum()
+    if total == 0:
+        return {"acc": 0.0, "f1": 0.0, "precision": 0.0, "recall": 0.0}
+    tp = np.diag(m)
+    support = m.sum(axis=1)       # occurrences in the targets
+    predicted = m.sum(axis=0)     # occurrences in the predictions
+    with np.errstate(divide="ignore", invalid="ignore"):
+        precision = np.where(predicted > 0, tp / predicted, 0.0)
+        recall = np.where(support > 0, tp / support, 0.0)
+        f1 = np.where(precision + recall > 0, 2 * precision * recall / (precision + recall), 0.0)
+    w = support / total  # labels that only occur in the predictions carry weight 0
+    return {"acc": float(tp.sum() / total), "f1": float((w * f1).sum()), "precision": float((w * precision).sum()),
+            "recall": float((w * recall).sum())}
+
+
+def _host_confusion(outputs: torch.Tensor, targets: torch.Tensor) -> np.ndarray:
+    """Host-side bookkeeping for tensors that already live on the CPU (metric logic, not the hot path)."""
+    out = outputs.detach().numpy()
+    tgt = targets.detach().numpy().reshape(-1)
+    if out.ndim == 1:
+        out = out.reshape(-1, 1)
+    if out.shape[1] == 1:
+        pred, truth, k = (out[:, 0] > 0.5).astype(np.int64), (tgt > 0.5).astype(np.int64), 2
+    else:
+        pred, truth = out.argmax(axis=1), tgt.astype(np.int64)
+        k = int(max(out.shape[1], truth.max(initial=0) + 1))
+    return np.bincount(truth * k + pred, minlength=k * k).reshape(k, k)
+
+
+def compute_metrics(outputs: torch.Tensor, targets: torch.Tensor) -> Dict[str, float]:
+    """Same contract as the reference (evaluate.py:23-59).  GPU tensors are scored by the HIP kernel."""
+    if outputs.is_cuda:
+        logits = outputs.detach().to(torch.float32)
+        if logits.dim() == 1:
+            logits = logits.reshape(-1, 1)
+        labels = targets.detach().reshape(-1)
+        labels = (labels > 0.5).to(torch.int64) if logits.shape[1] == 1 else labels.to(torch.int64)
+        return metrics_from_confusion(_lib.confusion_accumulate(logits.contiguous(), labels.to(logits.device)).cpu().numpy())
+    return metrics_from_confusion(_host_confusion(outputs, targets))
+
+
+@torch.no_grad()
+def evaluate_model(model: torch.nn.Module, loader, loss_fn=None, device: Optional[torch.device] = None
+                   ) -> Tuple[float, Dict[str, float]]:
+    """Mean of the per-batch mean cross-entropies and the metrics over the whole loader (evaluate.py:62-87).
+    ``loss_fn`` is accepted and ignored, exactly like the reference.  One host read-back at the end."""
+    if device is None:
+        device = next(model.parameters()).device
+    confusion = None
+    losses = []
+    for images, labels in loader:
+        images = images.to(device, non_blocking=True)
+        labels = labels.to(device, non_blocking=True).long()
+        logits = model(images).float().contiguous()
+        _, loss, _ = _lib.cross_entropy(logits, labels, want_grad=False)
+        losses.append(loss)
+        if logits.shape[1] == 1:
+            labels = (labels > 0).long()
+        confusion = _lib.confusion_accumulate(logits, labels, confusion)
+    if not losses:
+        raise ValueError("evaluate_model: empty loader")
+    total = torch.stack(losses).double().sum().item()  # the single synchronisation
+    return total / len(losses), metrics_from_confusion(confusion.cpu().numpy())

@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -58,6 +58,7 @@ SIGNATURES = {
                                             _c_p, _c_p, _c_p, _c_p, _c_p,
                                             _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
     "nnue_cross_entropy": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_f, _c_p, _c_p, _c_p, _c_p]),
+    "nnue_confusion_accumulate": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_p, _c_p]),
     "nnue_sgd_scratch": (_c_i64, [_c_i64]),
     "nnue_sgd_step": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_int,
                                _c_p, _c_p, _c_i64, _c_p]),
@@ -549,6 +550,20 @@ def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, grad_scale: float 
     _call("nnue_cross_entropy", logits.data_ptr(), labels.data_ptr(), b, c, float(grad_scale), sample_loss.data_ptr(),
           loss.data_ptr(), _ptr(d_logits), _stream(logits))
     return sample_loss, loss, d_logits
+
+
+def confusion_accumulate(logits: torch.Tensor, labels: torch.Tensor, confusion: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """confusion[truth, pred] += 1 for every row of the batch (int64 [K, K], K = C or 2 when C == 1)."""
+    logits = _need(logits, torch.float32, "logits")
+    b, c = logits.shape
+    labels = _need(labels, torch.int64, "labels", (b,))
+    k = 2 if c == 1 else c
+    if confusion is None:
+        confusion = torch.zeros((k, k), dtype=torch.int64, device=logits.device)
+    else:
+        _need(confusion, torch.int64, "confusion", (k, k))
+    _call("nnue_confusion_accumulate", logits.data_ptr(), labels.data_ptr(), b, c, confusion.data_ptr(), _stream(logits))
+    return confusion
 
 
 def sgd_scratch_bytes(count: int) -> int:

@@ -1,0 +1,72 @@
+"""compute_metrics / evaluate_model against golden vectors from the reference's sklearn-based
+implementation.  The metric arithmetic and the host bookkeeping run everywhere; the HIP confusion kernel and
+the whole evaluate_model loop need the GPU."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import evaluate
+from conftest import load_npz
+
+NAMES = ("acc", "f1", "precision", "recall")
+
+
+def cases():
+    z = load_npz("eval_metrics.npz")
+    for name in sorted({k.split("/")[0] for k in z}):
+        yield name, torch.from_numpy(z[f"{name}/outputs"]), torch.from_numpy(z[f"{name}/targets"]), z[f"{name}/metrics"]
+
+
+def check(got, want, what):
+    for n, w in zip(NAMES, want):
+        assert abs(got[n] - w) <= 1e-12 + 1e-9 * abs(w), f"{what} {n}: {got[n]} vs {w}"
+
+
+def test_compute_metrics_matches_sklearn_on_host_tensors():
+    seen = 0
+    for name, outputs, targets, want in cases():
+        check(evaluate.compute_metrics(outputs, targets), want, name)
+        seen += 1
+    assert seen == 7
+
+
+def test_metrics_from_confusion_edge_cases():
+    assert evaluate.metrics_from_confusion(np.zeros((3, 3))) == {"acc": 0.0, "f1": 0.0, "precision": 0.0, "recall": 0.0}
+    m = evaluate.metrics_from_confusion([[5, 0], [0, 7]])
+    assert m == {"acc": 1.0, "f1": 1.0, "precision": 1.0, "recall": 1.0}
+    # a class that is only ever predicted has weight 0; a class never predicted has precision 0 (zero_division=0)
+    m = evaluate.metrics_from_confusion([[0, 4, 0], [0, 4, 0], [0, 0, 0]])
+    assert m["acc"] == 0.5 and abs(m["precision"] - 0.25) < 1e-15 and abs(m["recall"] - 0.5) < 1e-15
+
+
+@pytest.mark.gpu
+def test_compute_metrics_on_gpu_tensors():
+    for name, outputs, targets, want in cases():
+        check(evaluate.compute_metrics(outputs.cuda(), targets.cuda()), want, name + " (gpu)")
+    # accumulation over batches equals one big batch; 1-D outputs are treated as one column
+    from nnue_hip import lib
+    name, outputs, targets, _ = next(cases())
+    o, t = outputs.cuda(), targets.cuda()
+    conf = None
+    for i in range(0, o.shape[0], 50):
+        conf = lib.confusion_accumulate(o[i:i + 50].contiguous(), t[i:i + 50].contiguous(), conf)
+    assert torch.equal(conf, lib.confusion_accumulate(o, t)) and int(conf.sum()) == o.shape[0]
+    assert evaluate.compute_metrics(torch.tensor([0.9, 0.1, 0.7]).cuda(), torch.tensor([1, 0, 0]).cuda())["acc"] == pytest.approx(2 / 3)
+
+
+@pytest.mark.gpu
+def test_evaluate_model_matches_reference():
+    import nnue
+    z = load_npz("eval_model.npz")
+    cfg = json.loads(str(z["cfg"]))
+    model = nnue.NNUE(nnue.GridFeatureSet(cfg["grid"], cfg["fps"]), cfg["l1"], cfg["l2"], cfg["l3"], num_classes=cfg["classes"])
+    model.load_state_dict({k[6:]: torch.from_numpy(v) for k, v in z.items() if k.startswith("state/")})
+    model = model.cuda().eval()
+    loader = [(torch.from_numpy(z[f"images{i}"]), torch.from_numpy(z[f"labels{i}"])) for i in range(cfg["batches"])]
+    loss, metrics = evaluate.evaluate_model(model, loader, None, torch.device("cuda"))
+    assert abs(loss - float(z["loss"])) <= 1e-4 * max(1.0, abs(float(z["loss"])))
+    check(metrics, z["metrics"], "evaluate_model")  # same predictions -> identical metrics
+    with pytest.raises(ValueError):
+        evaluate.evaluate_model(model, [], None)
