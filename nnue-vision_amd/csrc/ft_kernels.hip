@@ -130,6 +130,35 @@ __global__ __launch_bounds__(256) void ft_forward_simple(const float* __restrict
   out[(size_t)b * L1 + col] = acc;
 }
 
+// Narrow tables (L1 <= 256, e.g. the reference's default 64-wide config): 1024 threads = (1024 / Lp) list
+// slices x Lp columns (Lp = L1 rounded up to a power of two); each slice walks every S-th entry, the
+// slices are combined through LDS in slice order (deterministic).
+__global__ __launch_bounds__(1024) void ft_forward_narrow(const float* __restrict__ W,
+                                                          const float* __restrict__ bias,
+                                                          const int* __restrict__ rows,
+                                                          const float* __restrict__ coef,
+                                                          const int* __restrict__ n, int cap, int L1, int Lp,
+                                                          float* __restrict__ out) {
+  extern __shared__ float red[];  // [slices][Lp]
+  const int b = blockIdx.x;
+  const int col = threadIdx.x % Lp, slice = threadIdx.x / Lp, S = 1024 / Lp;
+  const int cnt = n[b];
+  const int* __restrict__ r = rows + (size_t)b * cap;
+  const float* __restrict__ c = coef + (size_t)b * cap;
+  float acc = 0.f;
+  if (col < L1) {
+#pragma unroll 4
+    for (int k = slice; k < cnt; k += S) acc = fmaf(c[k], W[(size_t)r[k] * L1 + col], acc);
+  }
+  red[slice * Lp + col] = acc;
+  __syncthreads();
+  if (slice == 0 && col < L1) {
+    float tot = bias[col];
+    for (int s2 = 0; s2 < S; ++s2) tot += red[s2 * Lp + col];
+    out[(size_t)b * L1 + col] = tot;
+  }
+}
+
 // ------------------------------------------------------------------ backward: weight / bias
 // grid (F + 1, ceil(S/4)); block row f < F is table row f, f == F is the bias (coefficient 1
 // for every sample).  A wave scans the row's coefficients 64 samples at a time, ballots the
@@ -349,6 +378,11 @@ extern "C" int nnue_ft_forward(const float* weight, const float* bias, const int
     const int S = L1 / 256;
     hipLaunchKernelGGL(ft_forward_wide<8>, dim3(B, (S + 3) / 4), dim3(64 * (S < 4 ? S : 4)), 0, s, weight, bias,
                        rows, coef, n, cap, L1, out);
+  } else if (L1 <= 256) {
+    int Lp = 1;
+    while (Lp < L1) Lp <<= 1;
+    hipLaunchKernelGGL(ft_forward_narrow, dim3(B), dim3(1024), 1024 * sizeof(float), s, weight, bias, rows, coef, n, cap, L1, Lp,
+                       out);
   } else {
     hipLaunchKernelGGL(ft_forward_simple, dim3(B, (L1 + 255) / 256), dim3(256), 0, s, weight, bias, rows, coef, n,
                        cap, L1, out);
