@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 6
+#define NNUE_HIP_ABI_VERSION 7
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -244,6 +244,18 @@ int nnue_sgd_step(float* params, float* grads, float* momentum_buf, int64_t coun
                   float lr, float momentum, float weight_decay, float max_norm, float grad_scale,
                   int first_step, float* norm_out, void* scratch, int64_t scratch_bytes,
                   nnue_stream_t stream);
+
+/* clip_grad_norm_ + torch.optim.Adam(lr, weight_decay) on flat buffers -- the optimizer create_optimizer picks
+ * when optimizer_type != "sgd" (train.py:363-366, :465-470; torch defaults betas (0.9, 0.999), eps 1e-8, L2
+ * weight decay added to the gradient, no amsgrad):
+ *   g <- clip * grad_scale * g + wd * p ; m <- b1 m + (1-b1) g ; v <- b2 v + (1-b2) g^2
+ *   p <- p - lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * t = ++step_counter[0] is kept in device memory so the call takes no per-step host argument (hipGraph replay).
+ * scratch >= nnue_sgd_scratch(count) bytes; norm_out may be NULL. */
+int nnue_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int32_t* step_counter,
+                   int64_t count, float lr, float beta1, float beta2, float eps, float weight_decay,
+                   float max_norm, float grad_scale, float* norm_out,
+                   void* scratch, int64_t scratch_bytes, nnue_stream_t stream);
 
 #ifdef __cplusplus
 }

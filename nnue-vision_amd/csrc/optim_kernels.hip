@@ -137,7 +137,82 @@ __global__ __launch_bounds__(256) void sgd_apply_kernel(float* __restrict__ p, c
   }
 }
 
+// Adam (torch.optim.Adam defaults: L2 weight decay folded into the gradient, bias-corrected moments, no
+// amsgrad).  The step number lives in device memory (step_counter[0], incremented here by the norm kernel's
+// first thread) so that the launch has no changing host argument and can be replayed from a hipGraph.
+__global__ __launch_bounds__(256) void sqnorm_stage1_count(const float* __restrict__ g, int64_t count, float scale,
+                                                           float* __restrict__ partial, int* __restrict__ step_counter) {
+  __shared__ float red[4];
+  if (blockIdx.x == 0 && threadIdx.x == 0) step_counter[0] += 1;
+  float acc = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+    const float v = g[i] * scale;
+    acc = fmaf(v, v, acc);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void adam_apply_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v, int64_t count,
+                                                         float lr, float beta1, float beta2, float eps, float wd,
+                                                         float max_norm, float scale, const int* __restrict__ step_counter,
+                                                         const float* __restrict__ partial, int nparts,
+                                                         float* __restrict__ norm_out) {
+  __shared__ double red[4];
+  __shared__ float coef_s;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) acc += (double)partial[i];
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float norm = (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
+    if (norm_out && blockIdx.x == 0) *norm_out = norm;
+    coef_s = max_norm > 0.0f ? fminf(max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+  }
+  __syncthreads();
+  const float gs = coef_s * scale;
+  const int t = step_counter[0];
+  const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+    const float w = p[i];
+    const float gi = fmaf(wd, w, g[i] * gs);
+    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = w - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+  }
+}
+
 }  // namespace
+
+extern "C" int nnue_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int32_t* step_counter, int64_t count,
+                              float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm, float grad_scale,
+                              float* norm_out, void* scratch, int64_t scratch_bytes, nnue_stream_t stream) {
+  NNUE_REQUIRE(params && grads && exp_avg && exp_avg_sq && step_counter && scratch, NNUE_E_ARG, "nnue_adam_step: null pointer");
+  NNUE_REQUIRE(count > 0, NNUE_E_ARG, "nnue_adam_step: count must be positive");
+  NNUE_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps > 0.f, NNUE_E_ARG,
+               "nnue_adam_step: betas must be in [0,1) and eps > 0");
+  NNUE_REQUIRE(scratch_bytes >= nnue_sgd_scratch(count), NNUE_E_SCRATCH, "nnue_adam_step: scratch %lld < %lld bytes",
+               (long long)scratch_bytes, (long long)nnue_sgd_scratch(count));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* partial = static_cast<float*>(scratch);
+  hipLaunchKernelGGL(sqnorm_stage1_count, dim3(kNormBlocks), dim3(256), 0, s, grads, count, grad_scale, partial, step_counter);
+  int blocks = (int)((count + 1023) / 1024);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adam_apply_kernel, dim3(blocks), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps,
+                     weight_decay, max_norm, grad_scale, step_counter, partial, kNormBlocks, norm_out);
+  return nnue_launch_status("nnue_adam_step");
+}
 
 extern "C" int nnue_cross_entropy(const float* logits, const int64_t* labels, int B, int C, float grad_scale,
                                   float* sample_loss, float* loss, float* d_logits, nnue_stream_t stream) {

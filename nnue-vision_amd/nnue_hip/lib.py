@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -60,6 +60,8 @@ SIGNATURES = {
     "nnue_cross_entropy": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_f, _c_p, _c_p, _c_p, _c_p]),
     "nnue_confusion_accumulate": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_p, _c_p]),
     "nnue_sgd_scratch": (_c_i64, [_c_i64]),
+    "nnue_adam_step": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f,
+                                _c_p, _c_p, _c_i64, _c_p]),
     "nnue_sgd_step": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_int,
                                _c_p, _c_p, _c_i64, _c_p]),
 }
@@ -580,3 +582,20 @@ def sgd_step(params: torch.Tensor, grads: torch.Tensor, momentum_buf: Optional[t
     _call("nnue_sgd_step", params.data_ptr(), grads.data_ptr(), _ptr(momentum_buf), params.numel(), float(lr),
           float(momentum), float(weight_decay), float(max_norm), float(grad_scale), int(bool(first_step)),
           _ptr(norm_out), scratch.data_ptr(), scratch.numel(), _stream(params))
+
+
+def adam_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
+              step_counter: torch.Tensor, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+              max_norm: float = 0.0, grad_scale: float = 1.0, norm_out: Optional[torch.Tensor] = None,
+              scratch: Optional[torch.Tensor] = None) -> None:
+    params = _need(params, torch.float32, "flat params")
+    shape = tuple(params.shape)
+    grads = _need(grads, torch.float32, "flat grads", shape)
+    _need(exp_avg, torch.float32, "exp_avg", shape)
+    _need(exp_avg_sq, torch.float32, "exp_avg_sq", shape)
+    _need(step_counter, torch.int32, "step counter", (1,))
+    if scratch is None:
+        scratch = torch.empty((sgd_scratch_bytes(params.numel()),), dtype=torch.uint8, device=params.device)
+    _call("nnue_adam_step", params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+          step_counter.data_ptr(), params.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+          float(max_norm), float(grad_scale), _ptr(norm_out), scratch.data_ptr(), scratch.numel(), _stream(params))

@@ -112,13 +112,16 @@ class NnueTrainer:
 
     def __init__(self, model, batch_size: int, image_hw: Tuple[int, int], lr: float, momentum: float = 0.0,
                  weight_decay: float = 0.0, max_grad_norm: float = 0.0, group=None, use_graph: bool = True,
-                 input_slots: int = 1):
+                 input_slots: int = 1, optimizer: str = "sgd", betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8):
         lib.load()
         p0 = next(model.parameters())
         if not p0.is_cuda:
             raise lib.NnueHipError("NnueTrainer needs the model on the GPU (no CPU fallback)")
         self.model, self.dev = model, p0.device
         self.lr, self.momentum, self.weight_decay, self.max_grad_norm = lr, momentum, weight_decay, max_grad_norm
+        if optimizer not in ("sgd", "adam"):
+            raise ValueError(f"optimizer must be 'sgd' or 'adam', got {optimizer!r}")
+        self.optimizer, self.betas, self.eps = optimizer, betas, eps
         self.dp = DataParallel(group)
         self.B, (self.H, self.W) = batch_size, image_hw
         self.stride = int(model.conv.stride[0])
@@ -136,7 +139,11 @@ class NnueTrainer:
         state = {k: p.detach() for k, p in model.named_parameters() if k not in SKIP}
         self.flat_params = self.layout.pack(state)
         self.flat_grads = torch.zeros(self.layout.count, **f32)
-        self.flat_momentum = torch.zeros(self.layout.count, **f32) if momentum else None
+        self.flat_momentum = torch.zeros(self.layout.count, **f32) if (momentum and optimizer == "sgd") else None
+        # Adam state (torch.optim.Adam semantics); the step number lives on the device so the update graph replays
+        self.flat_exp_avg = torch.zeros(self.layout.count, **f32) if optimizer == "adam" else None
+        self.flat_exp_avg_sq = torch.zeros(self.layout.count, **f32) if optimizer == "adam" else None
+        self.adam_step_count = torch.zeros(1, dtype=torch.int32, device=self.dev) if optimizer == "adam" else None
         self.dp.broadcast(self.flat_params)  # identical replicas even if ranks were seeded differently
         self.p = self.layout.views(self.flat_params)
         self.g = self.layout.views(self.flat_grads)
@@ -251,9 +258,18 @@ class NnueTrainer:
         for name in self.SEGMENTS:
             self._segment(name)
 
-    def _update(self, first: bool) -> None:
-        lib.sgd_step(self.flat_params, self.flat_grads, self.flat_momentum, self.lr, self.momentum, self.weight_decay,
-                     self.max_grad_norm, self.dp.grad_scale, first, self.grad_norm, self.sgd_scratch)
+    def _update(self, first: bool, grad_scale: Optional[float] = None) -> None:
+        scale = self.dp.grad_scale if grad_scale is None else grad_scale
+        if self.optimizer == "adam":
+            lib.adam_step(self.flat_params, self.flat_grads, self.flat_exp_avg, self.flat_exp_avg_sq, self.adam_step_count,
+                          self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm, scale, self.grad_norm,
+                          self.sgd_scratch)
+        else:
+            lib.sgd_step(self.flat_params, self.flat_grads, self.flat_momentum, self.lr, self.momentum, self.weight_decay,
+                         self.max_grad_norm, scale, first, self.grad_norm, self.sgd_scratch)
+
+    def _optimizer_buffers(self):
+        return [t for t in (self.flat_momentum, self.flat_exp_avg, self.flat_exp_avg_sq, self.adam_step_count) if t is not None]
 
     def _capture(self, fn) -> torch.cuda.CUDAGraph:
         """Captures fn(main_stream) into a graph; fn may fork work onto self._s1 / self._s2 with events."""
@@ -309,19 +325,16 @@ class NnueTrainer:
                     self._segment(name)
                 self._plan_seg[name] = list(calls)
             self._plan_local = [c for name in self.SEGMENTS for c in self._plan_seg[name]]
-            keep = (self.flat_params.clone(), self.flat_grads.clone(),
-                    None if self.flat_momentum is None else self.flat_momentum.clone(), self.grad_norm.clone())
+            live = [self.flat_params, self.flat_grads, self.grad_norm] + self._optimizer_buffers()
+            keep = [t.clone() for t in live]  # recording executes the updates: put everything back afterwards
             with lib.record_calls() as calls:
                 self._update(True)
             self._plan_update_first = list(calls)
             with lib.record_calls() as calls:
                 self._update(False)
             self._plan_update = list(calls)
-            self.flat_params.copy_(keep[0])
-            self.flat_grads.copy_(keep[1])
-            if keep[2] is not None:
-                self.flat_momentum.copy_(keep[2])
-            self.grad_norm.copy_(keep[3])
+            for t, k in zip(live, keep):
+                t.copy_(k)
         return self._plan_local, self._plan_update_first, self._plan_update
 
     def _seg_plan(self, slot: int, name: str):
@@ -343,11 +356,26 @@ class NnueTrainer:
         list}) the step runs eagerly from the recorded plan and brackets the named calls with HIP events on the
         launch stream (bench.py's per-kernel durations)."""
         buf_images, buf_labels = self.inputs[slot]
+        ragged = None
         if images is not None:
-            if tuple(images.shape) != tuple(buf_images.shape) or labels is None or tuple(labels.shape) != (self.B,):
+            if labels is None or images.shape[1:] != buf_images.shape[1:] or labels.shape[0] != images.shape[0] \
+                    or not 0 < images.shape[0] <= self.B:
                 raise ValueError(f"trainer was built for images {tuple(buf_images.shape)} / labels ({self.B},)")
-            buf_images.copy_(images, non_blocking=True)
-            buf_labels.copy_(labels, non_blocking=True)
+            n = images.shape[0]
+            if n == self.B:
+                buf_images.copy_(images, non_blocking=True)
+                buf_labels.copy_(labels, non_blocking=True)
+            else:
+                # short last batch of an epoch: pad with blank images whose label -1 the loss kernel ignores (zero
+                # loss, zero gradient row); the kernels divide by B, the exact mean over the n real samples is
+                # restored by scaling gradients and loss with B/n
+                if self.dp.world > 1:
+                    raise ValueError("ragged batches are only supported with a single rank")
+                ragged = self.B / n
+                buf_images.zero_()
+                buf_images[:n].copy_(images, non_blocking=True)
+                buf_labels.fill_(-1)
+                buf_labels[:n].copy_(labels, non_blocking=True)
         if self._plan_local is None and slot != 0:
             self.inputs[0][0].copy_(buf_images)
             self.inputs[0][1].copy_(buf_labels)
@@ -383,6 +411,10 @@ class NnueTrainer:
             small = self.dp.allreduce_sum(self.flat_grads[:self.bucket_split], async_op=True)
             big.wait()
             small.wait()
+        if ragged is not None:
+            self._update(first, grad_scale=self.dp.grad_scale * ragged)
+            self.steps_done += 1
+            return self.loss * ragged
         if first:
             lib.run_plan(upd_first, stream, timers)
         elif graphs:
@@ -391,6 +423,28 @@ class NnueTrainer:
             lib.run_plan(upd, stream, timers)
         self.steps_done += 1
         return self.loss
+
+    def optimizer_state_dict(self) -> dict:
+        """The optimizer state in torch.optim's own state_dict format (SGD momentum buffers, or Adam's step /
+        exp_avg / exp_avg_sq), indexed like ``model.parameters()`` -- what checkpoint_manager.py:45-51 stores and
+        ``optimizer.load_state_dict`` (checkpoint_manager.py:75-85) expects."""
+        params = list(self.model.parameters())
+        if self.optimizer == "adam":
+            opt = torch.optim.Adam(params, lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay)
+        else:
+            opt = torch.optim.SGD(params, lr=self.lr, momentum=self.momentum, weight_decay=self.weight_decay)
+        sd = opt.state_dict()
+        if self.steps_done == 0:
+            return sd
+        index = {k: i for i, (k, _) in enumerate(self.model.named_parameters())}
+        for k in self.layout.names:
+            if self.optimizer == "adam":
+                sd["state"][index[k]] = {"step": torch.tensor(float(self.steps_done)),
+                                         "exp_avg": self.layout.views(self.flat_exp_avg)[k].clone(),
+                                         "exp_avg_sq": self.layout.views(self.flat_exp_avg_sq)[k].clone()}
+            elif self.flat_momentum is not None:
+                sd["state"][index[k]] = {"momentum_buffer": self.layout.views(self.flat_momentum)[k].clone()}
+        return sd
 
     @torch.no_grad()
     def evaluate(self, images: torch.Tensor) -> torch.Tensor:

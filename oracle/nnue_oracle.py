@@ -374,6 +374,30 @@ def sgd_step(params: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor],
     return total
 
 
+def adam_step(params: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor], state: Dict[str, dict], lr: float,
+              weight_decay: float, max_grad_norm: float, betas=(0.9, 0.999), eps: float = 1e-8) -> torch.Tensor:
+    """clip_grad_norm_ + one torch.optim.Adam(lr, weight_decay) step, the optimizer create_optimizer builds when
+    optimizer_type != "sgd" (train.py:363-366, :465-470).  Returns the pre-clip norm."""
+    keys = [k for k in TRAINABLE_KEYS if k in grads]
+    total = torch.zeros(())
+    coef = torch.ones(())
+    if max_grad_norm and max_grad_norm > 0:
+        total, coef = clip_coefficient([grads[k] for k in keys], max_grad_norm)
+    b1, b2 = betas
+    for k in keys:
+        st = state.setdefault(k, {"step": 0, "m": torch.zeros_like(params[k]), "v": torch.zeros_like(params[k])})
+        st["step"] += 1
+        g = grads[k] * coef
+        if weight_decay:
+            g = g + weight_decay * params[k]
+        st["m"] = b1 * st["m"] + (1 - b1) * g
+        st["v"] = b2 * st["v"] + (1 - b2) * g * g
+        bc1, bc2 = 1 - b1 ** st["step"], 1 - b2 ** st["step"]
+        denom = st["v"].sqrt() / math.sqrt(bc2) + eps
+        params[k] = params[k] - (lr / bc1) * st["m"] / denom
+    return total
+
+
 # --------------------------------------------------------------------------
 # parameter initialisation in the reference's RNG order (nnue.py:486-507, :683-684, :728-734)
 # --------------------------------------------------------------------------

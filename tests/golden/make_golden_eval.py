@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Golden vectors for the evaluation row, generated from the REAL reference:
+"""Golden vectors for the widened rows (SURVEY section 8f.1 evaluation, 8f.2 Adam step), generated from the REAL reference:
 evaluate.compute_metrics (sklearn scorers, evaluate.py:23-59) and evaluate.evaluate_model (evaluate.py:62-87)
 on the reference NNUE, CPU.  Build container only:
 
@@ -77,6 +77,37 @@ def model_case():
     print(f"evaluate_model: seed+{seed} loss {loss:.6f} metrics {metrics} min_gap {gap:.2e} distinct predictions {preds.unique().numel()}")
 
 
+def adam_case(steps=3):
+    """train.py:359-366 with the optimizer create_optimizer builds for optimizer_type != "sgd" (train.py:465-470):
+    torch.optim.Adam(model.parameters(), lr, weight_decay), plus clip_grad_norm_(1.0)."""
+    cfg = dict(grid=10, fps=8, input_size=32, image=32, l1=64, l2=32, l3=8, classes=10, batch=8)
+    torch.manual_seed(300)
+    model = ref_nnue.NNUE(ref_nnue.GridFeatureSet(cfg["grid"], cfg["fps"]), cfg["l1"], cfg["l2"], cfg["l3"], num_classes=cfg["classes"])
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=2e-4)
+    out = {f"state0/{k}": v.numpy().copy() for k, v in model.state_dict().items()}
+    out["cfg"] = json.dumps(dict(cfg, model_seed=300, lr=1e-3, weight_decay=2e-4, max_grad_norm=1.0, stride=model.conv.stride[0]))
+    model.train()
+    for s in range(steps):
+        g = torch.Generator().manual_seed(6000 + s)
+        images = torch.randn(cfg["batch"], 3, 32, 32, generator=g)
+        labels = torch.randint(0, cfg["classes"], (cfg["batch"],), generator=g)
+        opt.zero_grad()
+        loss = torch.nn.functional.cross_entropy(model(images), labels.long())
+        loss.backward()
+        norm = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        out[f"images{s}"], out[f"labels{s}"] = images.numpy(), labels.numpy()
+        out[f"loss{s}"], out[f"gradnorm{s}"] = np.float32(loss.item()), np.float32(norm.item())
+        for k, v in model.state_dict().items():
+            out[f"state{s + 1}/{k}"] = v.numpy().copy()
+    np.savez_compressed(OUT / "step_adam_c1arch.npz", **out)
+    print("adam trajectory losses", [float(out[f"loss{s}"]) for s in range(steps)])
+
+
 if __name__ == "__main__":
-    metric_cases()
-    model_case()
+    if "--adam-only" in sys.argv:
+        adam_case()
+    else:
+        metric_cases()
+        model_case()
+        adam_case()

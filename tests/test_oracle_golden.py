@@ -128,3 +128,21 @@ def test_quantiser_and_size_formula(nnue_index):
     assert orc.nnue_file_size(256, 4, 64, 4, 8, 10) == nnue_index["nnue_grid8.nnue"]["size"] == 38204
     assert orc.nnue_file_size(800, 8, 64, 32, 8, 10) == nnue_index["nnue_c1arch.nnue"]["size"] == 110312
     assert orc.nnue_file_size(800, 8, 1024, 128, 32, 10) == nnue_index["c2arch_seed0"]["size"] == 2836856
+
+
+def test_adam_steps_match_reference():
+    """oracle.adam_step against clip_grad_norm_ + torch.optim.Adam run on the reference model."""
+    z = load_npz("step_adam_c1arch.npz")
+    cfg = json.loads(str(z["cfg"]))
+    params = {k[7:]: torch.from_numpy(v) for k, v in z.items() if k.startswith("state0/")}
+    state = {}
+    for s in range(3):
+        images, labels = torch.from_numpy(z[f"images{s}"]), torch.from_numpy(z[f"labels{s}"])
+        _, loss, grads, _ = orc.loss_and_grads_explicit(params, images, labels, cfg["stride"])
+        assert abs(float(loss) - float(z[f"loss{s}"])) <= 5e-5 * max(1.0, abs(float(z[f"loss{s}"])))
+        norm = orc.adam_step(params, grads, state, cfg["lr"], cfg["weight_decay"], cfg["max_grad_norm"])
+        assert abs(float(norm) - float(z[f"gradnorm{s}"])) <= 5e-5 * float(z[f"gradnorm{s}"])
+        for k in params:
+            ref = torch.from_numpy(z[f"state{s + 1}/{k}"])
+            # Adam divides by sqrt(v): an element whose gradient is ~0 amplifies rounding, so compare on the update scale
+            assert float((params[k] - ref).abs().max()) <= 2e-5 + 1e-4 * float(ref.abs().max()), (s, k)
