@@ -190,7 +190,7 @@ __global__ __launch_bounds__(1024) void ftb_gather_kernel(const float* __restric
     for (int i = 0; i < 2; ++i) {  // one piece = 4 staged rows x 256 B = 1 KiB, lane-linear in LDS
       const int piece = wave * 2 + i;
       int r = t * kRT + piece * 4 + (lane >> 4);
-      r = r < n_src ? r : n_src - 1;  // rows past the end are never referenced by a list
+      r = r < n_src ? r : max(n_src - 1, 0);  // rows past the end are never referenced by a list (row 0 always exists)
       dma16(src + (size_t)r * L1 + blockIdx.y * kTC + l16 * 4, base + piece * 1024);
     }
     if (lists_mine) {  // piece = 4 list records of 256 B
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(1024) void ftb_gather_kernel(const float* __restric
     if (coef_mine) {
       const int h = wave - (kWaves - 2);
       int r = t * kRT + h * 64 + lane;
-      r = r < n_src ? r : n_src - 1;
+      r = r < n_src ? r : max(n_src - 1, 0);
       dma4(sink + r, base + kSlotData + kListBytes + h * 256);
     }
   };
@@ -226,6 +226,7 @@ __global__ __launch_bounds__(1024) void ftb_gather_kernel(const float* __restric
   for (int t = t_lo; t < t_hi; ++t) {
     const int slot = (NBUF > 1) ? (t - t_lo) % NBUF : 0;
     wait_tiles_in_flight(NBUF > 1 && t + 1 < t_hi);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's own LDS traffic (zero rows, tile t-1 reads) has landed
     __builtin_amdgcn_s_barrier();  // tile t is complete in LDS; every wave is done with tile t-1
     asm volatile("" ::: "memory");
     if (NBUF > 1 && t + 2 < t_hi) issue_tile(t + 2, (t + 2 - t_lo) % NBUF);  // refills the slot tile t-1 used
