@@ -417,7 +417,20 @@ __global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restric
                                                           float* __restrict__ d_b3, float* __restrict__ d_w2,
                                                           float* __restrict__ d_b2, float* __restrict__ d_b1,
                                                           const float* __restrict__ sample_loss,
-                                                          float* __restrict__ loss_out) {
+                                                          float* __restrict__ loss_out, int wgrad_blocks,
+                                                          const float* __restrict__ slabs, int n_slabs,
+                                                          long long slab_count, float* __restrict__ d_w1) {
+  if ((int)blockIdx.x >= wgrad_blocks) {  // piggy-backed pass: fixed-order sum of the d_w1 split-K slabs
+    const long long i = ((long long)(blockIdx.x - wgrad_blocks) * 256 + threadIdx.x) * 4;
+    if (i >= slab_count) return;
+    float4 acc = *reinterpret_cast<const float4*>(slabs + i);
+    for (int s2 = 1; s2 < n_slabs; ++s2) {
+      const float4 v = *reinterpret_cast<const float4*>(slabs + (size_t)s2 * slab_count + i);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(d_w1 + i) = acc;
+    return;
+  }
   long long o = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int v3 = (L3 % 4 == 0) ? 4 : 1, v2 = (L2 % 4 == 0) ? 4 : 1;
@@ -683,7 +696,8 @@ extern "C" int nnue_classifier_backward(const float* x, int pairwise, const floa
   {
     const long long outs = (long long)C * (L3 % 4 == 0 ? L3 / 4 : L3) + (long long)L3 * (L2 % 4 == 0 ? L2 / 4 : L2) + C + L3 + L2;
     hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, s, d_logits, d_z2, d_z1, h1, h2, B,
-                       L2, L3, C, d_w3, d_b3, d_w2, d_b2, d_b1, (const float*)nullptr, (float*)nullptr);
+                       L2, L3, C, d_w3, d_b3, d_w2, d_b2, d_b1, (const float*)nullptr, (float*)nullptr,
+                       (int)((outs + 3) / 4), (const float*)nullptr, 0, 0ll, (float*)nullptr);
   }
   if (p.bww_mfma) {
     const long long waves = (long long)(L2 / 32) * (L1 / 64) * p.bww_ksplit;
@@ -784,21 +798,22 @@ extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const fl
     }
   }
   if (phases & 2) {  // needs phase 1's h1, h2, d_logits, d_z1, d_z2 (scratch) -- nothing downstream depends on it
-    const long long outs = (long long)C * (L3 % 4 == 0 ? L3 / 4 : L3) + (long long)L3 * (L2 % 4 == 0 ? L2 / 4 : L2) + C + L3 + L2 + 1;
-    hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, s, d_logits, d_z2, d_z1, h1, h2, B, L2, L3, C,
-                       d_w3, d_b3, d_w2, d_b2, d_b1, (const float*)sample_loss, loss);
+    const bool slab_pass = p.bww_mfma && p.bww_ksplit > 1;
     if (p.bww_mfma) {
       const long long waves = (long long)(L2 / 32) * (L1 / 64) * p.bww_ksplit;
-      float* target = p.bww_ksplit > 1 ? slabs : d_w1;
       hipLaunchKernelGGL(l1_backward_w_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, d_z1, B, L1, L2, p.bww_ksplit,
-                         p.bww_klen, target);
-      if (p.bww_ksplit > 1) {
-        const long long count = (long long)L2 * L1;
-        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, s, slabs, p.bww_ksplit, count, d_w1);
-      }
+                         p.bww_klen, slab_pass ? slabs : d_w1);
     } else {
       hipLaunchKernelGGL(l1_backward_w_simple, dim3(L2, (L1 + 255) / 256), dim3(256), 0, s, x, pairwise, d_z1, B, L1, L2, d_w1);
     }
+    // one launch: the small weight/bias gradients, the mean loss and (piggy-backed) the d_w1 slab sum
+    const long long outs = (long long)C * (L3 % 4 == 0 ? L3 / 4 : L3) + (long long)L3 * (L2 % 4 == 0 ? L2 / 4 : L2) + C + L3 + L2 + 1;
+    const int wgrad_blocks = (int)((outs + 3) / 4);
+    const long long count = (long long)L2 * L1;
+    const int slab_blocks = slab_pass ? (int)((count / 4 + 255) / 256) : 0;
+    hipLaunchKernelGGL(small_wgrad_kernel, dim3(wgrad_blocks + slab_blocks), dim3(256), 0, s, d_logits, d_z2, d_z1, h1, h2, B, L2, L3, C,
+                       d_w3, d_b3, d_w2, d_b2, d_b1, (const float*)sample_loss, loss, wgrad_blocks, (const float*)slabs,
+                       slab_pass ? p.bww_ksplit : 0, count, d_w1);
   }
   return nnue_launch_status("nnue_classifier_train_step");
 }
