@@ -120,3 +120,39 @@ def test_ftb_rejects_unsupported_width(hip):
     bits = hip.FeatureBits.empty(4, 32, 16, 64, DEV)
     with pytest.raises(hip.NnueHipError, match="not supported"):
         hip.ftb_forward(torch.zeros(16, 64, device=DEV), torch.zeros(64, device=DEV), bits)
+
+
+def test_c4_shaped_table_paths_agree(hip):
+    """BASELINE config 4 geometry (64 x 32 x 32 map = 65 536 positions = table rows, L1 = 1024): the LDS-staged
+    kernels (tile splitting + finish pass forward, one-slot variant backward) against the list kernels, and a
+    slice of the outputs against a float64 oracle."""
+    b, fps, gh, gw, f, l1 = 24, 64, 32, 32, 65536, 1024
+    gen = torch.Generator().manual_seed(44)
+    x = torch.randn(b, fps, gh, gw, generator=gen)
+    thr = torch.full((fps,), 0.1)
+    w = (torch.randn(f, l1, generator=gen) * 0.1).to(DEV)
+    bias = torch.zeros(l1, device=DEV)
+    up = torch.randn(b, l1, generator=gen).to(DEV)
+    xd, td = x.to(DEV), thr.to(DEV)
+    bits = hip.binarize_bits(xd, td, f, l1)
+    act = hip.binarize_features(xd, td, f)
+    assert torch.equal(bits.n, act.n)
+    out, ref_out = hip.ftb_forward(w, bias, bits), hip.ft_forward(w, bias, act)
+    # two fp32 summation orders over ~28 000 terms each (sequential in the list kernel, 4 x 4 partial sums here):
+    # their mutual distance is the summation-order effect at this size; the float64 slice below is the real bar
+    assert_close_logits(out, ref_out, "c4 forward", rtol=1e-3)
+    d_w, d_b = hip.ftb_backward_weight(up, bits)
+    l_w, l_b = hip.ft_backward_weight(up, act, f)
+    assert_close_grad(d_w, l_w, "c4 d_weight")
+    assert_close_grad(d_b, l_b, "c4 d_bias")
+    d_x = hip.ftb_backward_values(up, w, bits)
+    assert_close_grad(d_x, hip.ft_backward_values(up, w, act, fps * gh * gw), "c4 d_conv_out")
+    # float64 oracle on three samples
+    on = (x > 0.1).reshape(b, -1)
+    for s in (0, 11, 23):
+        ids = on[s].nonzero().flatten().to(DEV)
+        ref = w[ids].double().sum(0)
+        assert float((out[s].double() - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+        dots = (w[ids].double() @ up[s].double())
+        assert float((d_x[s][ids].double() - dots).abs().max()) <= 1e-4 * float(dots.abs().max())
+        assert int((d_x[s] != 0).sum()) <= ids.numel()

@@ -73,3 +73,23 @@ def test_flat_layout_alignment_and_roundtrip():
     flat = lay.pack(state)
     for k, v in lay.views(flat).items():
         assert torch.equal(v, state[k])
+
+
+def test_c4_shaped_step_list_and_lds_paths_agree(monkeypatch):
+    """One full training step at BASELINE config 4's architecture (224x224, 32x32x64 grid, 65 536 -> 1024/128/32 ->
+    1000) with both FeatureTransformer kernel families: same loss, same gradients."""
+    cfgs = {}
+    for path in ("list", "bits"):
+        monkeypatch.setenv("NNUE_FT_PATH", path)
+        torch.manual_seed(0)
+        model = nnue.NNUE(nnue.GridFeatureSet(32, 64), 1024, 128, 32, num_classes=1000, input_size=224).to(DEV)
+        tr = NnueTrainer(model, 8, (224, 224), lr=0.0, use_graph=False)
+        assert tr.use_bits == (path == "bits")
+        gen = torch.Generator().manual_seed(1)
+        images, labels = torch.randn(8, 3, 224, 224, generator=gen), torch.randint(0, 1000, (8,), generator=gen)
+        loss = tr.step(images.to(DEV), labels.to(DEV))
+        cfgs[path] = (float(loss), tr.flat_grads.clone(), tr.active_stats())
+        del tr, model
+    assert abs(cfgs["list"][0] - cfgs["bits"][0]) <= 1e-5 * max(1.0, abs(cfgs["list"][0]))
+    assert cfgs["list"][2] == cfgs["bits"][2] and cfgs["list"][2][0] > 20000  # ~28k active features per image
+    assert_close_grad(cfgs["bits"][1], cfgs["list"][1], "flat gradient")
