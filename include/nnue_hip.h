@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 7
+#define NNUE_HIP_ABI_VERSION 8
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -244,6 +244,18 @@ int nnue_sgd_step(float* params, float* grads, float* momentum_buf, int64_t coun
                   float lr, float momentum, float weight_decay, float max_norm, float grad_scale,
                   int first_step, float* norm_out, void* scratch, int64_t scratch_bytes,
                   nnue_stream_t stream);
+
+/* ---- input pipeline ------------------------------------------------------------------------------
+ * One batch of GenericVisionDataset.__getitem__ + collate (data/datasets.py:173-195, :358-372) from a uint8
+ * dataset resident in HBM: images_u8 [N,H,W,3], labels_all [N]; indices [B] select the samples.  Writes
+ * out [B,3,H,W] float32 = Normalize(ImageNet mean/std, max 255) of the (optionally augmented) pixels, CHW, and
+ * labels_out [B].  augment != 0 applies the reference's "light" policy: HorizontalFlip p=0.5,
+ * RandomBrightnessContrast(0.1, 0.1) p=0.2 (uint8 LUT semantics), CoarseDropout (one 5% x 5% hole, fill 0)
+ * p=0.2.  Random draws are a counter-based hash of (seed, step, dataset index): reproducible, but not
+ * albumentations' stream (parity unpinned for augment != 0; the plain path is an exact formula). */
+int nnue_load_batch(const uint8_t* images_u8, const int64_t* labels_all, const int64_t* indices,
+                    int B, int H, int W, int64_t N, int augment, uint64_t seed, uint64_t step,
+                    float* out, int64_t* labels_out, nnue_stream_t stream);
 
 /* clip_grad_norm_ + torch.optim.Adam(lr, weight_decay) on flat buffers -- the optimizer create_optimizer picks
  * when optimizer_type != "sgd" (train.py:363-366, :465-470; torch defaults betas (0.9, 0.999), eps 1e-8, L2

@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -59,6 +59,8 @@ SIGNATURES = {
                                             _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
     "nnue_cross_entropy": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_f, _c_p, _c_p, _c_p, _c_p]),
     "nnue_confusion_accumulate": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_p, _c_p]),
+    "nnue_load_batch": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_i64, _c_int, ctypes.c_uint64, ctypes.c_uint64,
+                                 _c_p, _c_p, _c_p]),
     "nnue_sgd_scratch": (_c_i64, [_c_i64]),
     "nnue_adam_step": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f,
                                 _c_p, _c_p, _c_i64, _c_p]),
@@ -599,3 +601,24 @@ def adam_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, 
     _call("nnue_adam_step", params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
           step_counter.data_ptr(), params.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
           float(max_norm), float(grad_scale), _ptr(norm_out), scratch.data_ptr(), scratch.numel(), _stream(params))
+
+
+def load_batch(images_u8: torch.Tensor, labels_all: torch.Tensor, indices: torch.Tensor, augment: bool, seed: int, step: int,
+               out: Optional[torch.Tensor] = None, labels_out: Optional[torch.Tensor] = None):
+    """uint8 [N,H,W,3] dataset + indices [B] -> normalised float32 [B,3,H,W] (+ light augmentation) and labels [B]."""
+    images_u8 = _need(images_u8, torch.uint8, "dataset images")
+    if images_u8.dim() != 4 or images_u8.shape[3] != 3:
+        raise ValueError(f"dataset images: expected uint8 [N,H,W,3], got {tuple(images_u8.shape)}")
+    n, h, w, _ = images_u8.shape
+    labels_all = _need(labels_all, torch.int64, "dataset labels", (n,))
+    indices = _need(indices, torch.int64, "indices")
+    b = indices.numel()
+    if out is None:
+        out = torch.empty((b, 3, h, w), dtype=torch.float32, device=images_u8.device)
+    elif tuple(out.shape) != (b, 3, h, w) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("load_batch: out must be a contiguous float32 [B,3,H,W] tensor")
+    if labels_out is None:
+        labels_out = torch.empty((b,), dtype=torch.int64, device=images_u8.device)
+    _call("nnue_load_batch", images_u8.data_ptr(), labels_all.data_ptr(), indices.data_ptr(), b, h, w, n, int(bool(augment)),
+          int(seed) & (2 ** 64 - 1), int(step) & (2 ** 64 - 1), out.data_ptr(), labels_out.data_ptr(), _stream(images_u8))
+    return out, labels_out

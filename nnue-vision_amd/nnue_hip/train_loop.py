@@ -28,6 +28,7 @@ import torch
 
 from . import lib
 from .trainer import NnueTrainer
+from .input_pipeline import GpuLoader, train_epoch
 
 
 class ConfigError(Exception):
@@ -77,22 +78,30 @@ def run_training(config, train_loader: Iterable, val_loader: Iterable, test_load
         raise lib.NnueHipError("training runs on the GPU only (no CPU fallback in this build)")
     device = torch.device("cuda", torch.cuda.current_device())
     model = build_model(config, device) if model is None else model.to(device)
-    first_images, _ = next(iter(train_loader))
-    batch, hw = int(config.batch_size), tuple(first_images.shape[2:])
+    in_place = isinstance(train_loader, GpuLoader)  # GPU-resident dataset: batches are written straight into the input slots
+    if in_place:
+        hw = train_loader.dataset.image_hw
+    else:
+        first_images, _ = next(iter(train_loader))
+        hw = tuple(first_images.shape[2:])
+    batch = int(config.batch_size)
     clip = float(config.max_grad_norm) if hasattr(config, "max_grad_norm") and config.max_grad_norm > 0 else 0.0
     if config.optimizer_type == "sgd":
         opt = dict(optimizer="sgd", momentum=float(config.momentum))
     else:
         opt = dict(optimizer="adam")
     trainer = NnueTrainer(model, batch, hw, lr=float(config.learning_rate), weight_decay=float(config.weight_decay),
-                          max_grad_norm=clip, use_graph=use_graph, **opt)
+                          max_grad_norm=clip, use_graph=use_graph, input_slots=2 if in_place else 1, **opt)
     result = TrainResult()
     ckpt_dir = Path(checkpoint_dir) if checkpoint_dir is not None else None
     for epoch in range(int(config.max_epochs)):
         model.train()
-        for images, labels in train_loader:
-            trainer.step(images.to(device, non_blocking=True), labels.to(device, non_blocking=True).long())
-            result.steps += 1
+        if in_place:
+            result.steps += train_epoch(trainer, train_loader)[1]
+        else:
+            for images, labels in train_loader:
+                trainer.step(images.to(device, non_blocking=True), labels.to(device, non_blocking=True).long())
+                result.steps += 1
         model.eval()
         train_loss, train_metrics = evaluate.evaluate_model(model, train_loader, None, device)
         val_loss, val_metrics = evaluate.evaluate_model(model, val_loader, None, device)
