@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--density", type=float, default=None,
+                    help="override visual_threshold per channel so about this fraction of features is active (SURVEY 8d sweep); "
+                         "default: the reference's 0.1 threshold (~0.43)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
@@ -126,6 +129,16 @@ def main():
     for images, labels in trainer.inputs:
         images.copy_(torch.randn(B, 3, cfg["image"], cfg["image"], generator=gen))
         labels.copy_(torch.randint(0, cfg["classes"], (B,), generator=gen))
+
+    if args.density is not None:
+        if not 0.0 < args.density < 1.0:
+            raise SystemExit("--density must be in (0, 1)")
+        with torch.no_grad():  # per-channel quantile of this rank's conv outputs on slot 0
+            conv = torch.nn.functional.conv2d(trainer.inputs[0][0][:min(B, 64)], model.conv.weight.detach(), stride=model.conv.stride, padding=1)
+            per_channel = conv.transpose(0, 1).flatten(1)
+            if per_channel.shape[1] > 1 << 20:
+                per_channel = per_channel[:, :: per_channel.shape[1] // (1 << 20) + 1]
+            model.visual_threshold.copy_(torch.quantile(per_channel, 1.0 - args.density, dim=1))
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -220,9 +233,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: NNUE {cfg['image']}x{cfg['image']} grid {cfg['grid']}x{cfg['grid']}x{cfg['fps']} "
                                    f"F={cfg['grid'] ** 2 * cfg['fps']} -> {cfg['l1']}/{cfg['l2']}/{cfg['l3']} -> {cfg['classes']}, "
-                                   f"batch {B}/GPU, SGD m0.9 wd2e-4 clip1.0",
+                                   f"batch {B}/GPU, SGD m0.9 wd2e-4 clip1.0" + (f", thresholds set for density {args.density}" if args.density is not None else ""),
                        "global_batch": B * world, "parallelism": f"dp{world}", "launch": "eager" if args.no_graph else "hipGraph",
                        "mean_active_features": round(n_mean, 1), "max_active_features": n_max,
+                       "active_density": round(n_mean / ((cfg["image"] - 1) // max(1, (cfg["image"] - 1) // (cfg["grid"] - 1)) + 1) ** 2 / cfg["fps"], 4),
                        "eager_ms_per_step_instrumented": round(eager_ms, 4), "loss_after": round(loss_after, 4)},
             "roofline": roofline,
             "kernels": kernels,

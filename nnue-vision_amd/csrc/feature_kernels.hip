@@ -182,6 +182,118 @@ __global__ __launch_bounds__(256) void ste_conv_backward_stage1(const float* __r
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// Position-tiled variant for fps <= 64 (every shipped configuration): the conv weight gradient is a dense
+// contraction dW[c][q] = sum_p d[p][c] * patch[p][q] over all B*Gh*Gw positions p, so it runs on the f32 MFMA
+// (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate).  A block walks 64-position tiles: the d tile
+// [fps x 64] and the im2col patch tile [27 x 64] are staged once into LDS (coalesced along positions; every
+// pixel is read once per block instead of once per channel), the threshold term d * k * s * (1 - s) is
+// accumulated per lane while d passes through registers, and each of the four waves contracts its 16 positions
+// for all channel tiles.  K (positions) is permuted identically on both operands (float4 along positions, MFMA
+// step t takes element t), which a sum does not care about.  One 28-vector per channel per block goes to stage 2.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int kStePos = 64;     // positions per tile
+constexpr int kSteLd = 68;      // LDS row stride in floats: 16 B aligned, rows 4 banks apart -> conflict-free b128 reads
+constexpr int kSteMaxBlocks = 1024;
+
+template <int MT>  // 16-channel tiles, fps <= 16 * MT
+__global__ __launch_bounds__(256) void ste_conv_backward_mfma(const float* __restrict__ img,
+                                                              const float* __restrict__ conv_out,
+                                                              const float* __restrict__ thr,
+                                                              const float* __restrict__ d_conv_out, int B, int H, int W,
+                                                              int fps, int stride, int Gh, int Gw, int tiles,
+                                                              float* __restrict__ partial) {
+  // staging tiles and the final cross-wave reduction buffer share LDS (the last tile ends with a barrier)
+  constexpr int kStage = (MT * 16 + 32) * kSteLd, kRed = 4 * MT * 8 * 64;
+  __shared__ __attribute__((aligned(16))) float smem[kStage > kRed ? kStage : kRed];
+  float (*d_lds)[kSteLd] = reinterpret_cast<float (*)[kSteLd]>(smem);
+  float (*p_lds)[kSteLd] = reinterpret_cast<float (*)[kSteLd]>(smem + MT * 16 * kSteLd);
+  float (*red)[MT * 8][64] = reinterpret_cast<float (*)[MT * 8][64]>(smem);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int G = Gh * Gw;
+  const int NP = B * G;
+  for (int i = threadIdx.x; i < MT * 16 * kSteLd; i += 256) (&d_lds[0][0])[i] = 0.0f;  // rows >= fps stay zero
+  for (int i = threadIdx.x; i < 32 * kSteLd; i += 256) (&p_lds[0][0])[i] = 0.0f;       // rows >= 27 stay zero
+  f32x4 acc[MT][2];
+  float tacc[MT * 4];  // this wave stages channels wave + 4 j
+#pragma unroll
+  for (int i = 0; i < MT; ++i) acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < MT * 4; ++j) tacc[j] = 0.0f;
+  __syncthreads();
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int p = tile * kStePos + lane;
+    const bool ok = p < NP;
+    const int b = ok ? p / G : 0;
+    const int hw = ok ? p - b * G : 0;
+#pragma unroll
+    for (int j = 0; j < MT * 4; ++j) {
+      const int c = wave + 4 * j;
+      if (c < fps) {
+        const size_t o = ((size_t)b * fps + c) * G + hw;
+        const float d = ok ? d_conv_out[o] : 0.0f;
+        const float cv = ok ? conv_out[o] : 0.0f;
+        const float s = 1.0f / (1.0f + __expf(-kSteSharpness * (cv - thr[c])));  // scalar load, cached
+        tacc[j] = fmaf(d, (kSteSharpness * s) * (1.0f - s), tacc[j]);
+        d_lds[c][lane] = d;
+      }
+    }
+    const int h = hw / Gw, x = hw - h * Gw;
+#pragma unroll
+    for (int rr = 0; rr < 7; ++rr) {
+      const int qq = wave + 4 * rr;  // wave-uniform patch term
+      if (qq < 27) {
+        const int ci = qq / 9, kh = (qq - ci * 9) / 3, kw = qq - ci * 9 - kh * 3;
+        const int iy = h * stride + kh - 1, ix = x * stride + kw - 1;
+        const bool in = ok && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        p_lds[qq][lane] = in ? img[(((size_t)b * 3 + ci) * H + iy) * W + ix] : 0.0f;
+      }
+    }
+    __syncthreads();
+    const int k0 = 16 * wave + 4 * q;
+    const float4 b0 = *reinterpret_cast<const float4*>(&p_lds[r][k0]);
+    const float4 b1 = *reinterpret_cast<const float4*>(&p_lds[16 + r][k0]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const float4 a = *reinterpret_cast<const float4*>(&d_lds[i * 16 + r][k0]);
+      acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc[i][0], 0, 0, 0);
+      acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc[i][1], 0, 0, 0);
+      acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc[i][0], 0, 0, 0);
+      acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc[i][1], 0, 0, 0);
+      acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0.z, acc[i][0], 0, 0, 0);
+      acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1.z, acc[i][1], 0, 0, 0);
+      acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, acc[i][0], 0, 0, 0);
+      acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, acc[i][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // the four waves hold disjoint position slices of the same [channel x term] tiles: sum them in wave order
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wave][(i * 2 + t) * 4 + e][lane] = acc[i][t][e];
+  __syncthreads();
+  float* __restrict__ out = partial + (size_t)blockIdx.x * fps * 28;
+  for (int o = threadIdx.x; o < MT * 16 * 32; o += 256) {
+    const int c = o >> 5, qq = o & 31;
+    if (c >= fps || qq >= 27) continue;
+    // accumulator register e of lane 16 * qd + rr holds D[row 4 * qd + e][col rr]
+    const int i = c >> 4, row = c & 15, t = qq >> 4, rr = qq & 15;
+    const int slot = (i * 2 + t) * 4 + (row & 3), ln = (row >> 2) * 16 + rr;
+    out[c * 28 + qq] = (red[0][slot][ln] + red[1][slot][ln]) + (red[2][slot][ln] + red[3][slot][ln]);
+  }
+#pragma unroll
+  for (int j = 0; j < MT * 4; ++j) {
+    float v = tacc[j];
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft);
+    if (lane == 0 && wave + 4 * j < fps) out[(wave + 4 * j) * 28 + 27] = v;
+  }
+}
+
 // one wave per (channel, term): lanes stride over the chunk partials, fixed-shape tree sum
 __global__ __launch_bounds__(256) void ste_conv_backward_stage2(const float* __restrict__ partial, int chunks, int fps,
                                                                 float* __restrict__ d_thr, float* __restrict__ d_weight) {
@@ -207,6 +319,11 @@ int ste_chunks(int B, int fps) {
   if (chunks < 1) chunks = 1;
   if (chunks > B) chunks = B;
   return chunks;
+}
+
+int64_t ste_mfma_blocks(int64_t positions) {
+  const int64_t tiles = (positions + kStePos - 1) / kStePos;
+  return tiles < kSteMaxBlocks ? (tiles > 0 ? tiles : 1) : kSteMaxBlocks;
 }
 
 }  // namespace
@@ -246,10 +363,10 @@ extern "C" int nnue_binarize_features(const float* conv_out, const float* thr, i
 }
 
 extern "C" int64_t nnue_ste_conv_backward_scratch(int B, int fps, int Gh, int Gw) {
-  (void)Gh;
-  (void)Gw;
   if (B <= 0 || fps <= 0) return 0;
-  return (int64_t)ste_chunks(B, fps) * fps * 28 * sizeof(float);
+  int64_t blocks = ste_chunks(B, fps);
+  if (fps <= 64 && Gh > 0 && Gw > 0) blocks = ste_mfma_blocks((int64_t)B * Gh * Gw);
+  return blocks * fps * 28 * (int64_t)sizeof(float);
 }
 
 extern "C" int nnue_ste_conv_backward(const float* images, const float* conv_out, const float* thr,
@@ -263,13 +380,32 @@ extern "C" int nnue_ste_conv_backward(const float* images, const float* conv_out
   NNUE_REQUIRE(scratch_bytes >= nnue_ste_conv_backward_scratch(B, fps, Gh, Gw), NNUE_E_SCRATCH,
                "nnue_ste_conv_backward: scratch %lld < %lld bytes", (long long)scratch_bytes,
                (long long)nnue_ste_conv_backward_scratch(B, fps, Gh, Gw));
-  const int chunks = ste_chunks(B, fps);
-  const int spc = (B + chunks - 1) / chunks;
-  NNUE_REQUIRE((long long)spc * Gh * Gw < (1ll << 31), NNUE_E_SHAPE, "nnue_ste_conv_backward: chunk too large");
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* partial = static_cast<float*>(scratch);
-  hipLaunchKernelGGL(ste_conv_backward_stage1, dim3(fps, chunks), dim3(256), 0, s, images, conv_out, thr, d_conv_out, B, H,
-                     W, fps, stride, Gh, Gw, spc, partial);
+  int chunks;
+  if (fps <= 64) {
+    const long long NP = (long long)B * Gh * Gw;
+    NNUE_REQUIRE(NP < (1ll << 31) - 64 && (long long)B * fps * Gh * Gw < (1ll << 40), NNUE_E_SHAPE,
+                 "nnue_ste_conv_backward: too many positions");
+    const int tiles = (int)((NP + kStePos - 1) / kStePos);
+    chunks = (int)ste_mfma_blocks(NP);
+#define NNUE_STE_LAUNCH(MT)                                                                                              \
+  hipLaunchKernelGGL(ste_conv_backward_mfma<MT>, dim3(chunks), dim3(256), 0, s, images, conv_out, thr, d_conv_out, B, H, W, \
+                     fps, stride, Gh, Gw, tiles, partial)
+    switch ((fps + 15) / 16) {
+      case 1: NNUE_STE_LAUNCH(1); break;
+      case 2: NNUE_STE_LAUNCH(2); break;
+      case 3: NNUE_STE_LAUNCH(3); break;
+      default: NNUE_STE_LAUNCH(4); break;
+    }
+#undef NNUE_STE_LAUNCH
+  } else {
+    chunks = ste_chunks(B, fps);
+    const int spc = (B + chunks - 1) / chunks;
+    NNUE_REQUIRE((long long)spc * Gh * Gw < (1ll << 31), NNUE_E_SHAPE, "nnue_ste_conv_backward: chunk too large");
+    hipLaunchKernelGGL(ste_conv_backward_stage1, dim3(fps, chunks), dim3(256), 0, s, images, conv_out, thr, d_conv_out, B, H,
+                       W, fps, stride, Gh, Gw, spc, partial);
+  }
   hipLaunchKernelGGL(ste_conv_backward_stage2, dim3((fps * 28 + 3) / 4), dim3(256), 0, s, partial, chunks, fps, d_thr, d_weight);
   return nnue_launch_status("nnue_ste_conv_backward");
 }

@@ -9,6 +9,7 @@ import json
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 import nnue_oracle as orc
 from conftest import MODEL_CASES, assert_close_grad, assert_close_logits, golden_model, load_npz
@@ -175,6 +176,32 @@ def test_ste_conv_backward(hip, name):
     ref_w = orc.conv_weight_grad(data["images"].double(), d.double(), cfg["stride"], params["conv.weight"].shape)
     assert_close_grad(d_thr, ref_thr, "d_thr")
     assert_close_grad(d_w, ref_w, "d_conv_weight")
+
+
+STE_SHAPES = [  # B, H, W, fps, stride: every channel-tile count of the MFMA kernel, the generic kernel (fps > 64),
+    # non-square maps, tiles crossing sample boundaries, a single position, C2's and C4's shapes
+    (1, 3, 3, 1, 3), (2, 32, 32, 3, 3), (5, 17, 23, 8, 2), (64, 32, 32, 8, 3), (3, 40, 40, 17, 4), (4, 33, 31, 33, 5),
+    (2, 64, 64, 50, 7), (3, 224, 224, 64, 7), (2, 20, 20, 70, 2), (7, 96, 96, 16, 1),
+]
+
+
+@pytest.mark.parametrize("shape", STE_SHAPES)
+@pytest.mark.parametrize("density", (0.03, 0.45, 1.0))
+def test_ste_conv_backward_shapes(hip, shape, density):
+    b, h, w, fps, stride = shape
+    gen = torch.Generator().manual_seed(b * 1000 + fps)
+    images = torch.randn(b, 3, h, w, generator=gen)
+    weight = torch.randn(fps, 3, 3, 3, generator=gen) * 0.2
+    x = F.conv2d(images, weight, stride=stride, padding=1)
+    thr = torch.randn(fps, generator=gen) * 0.1
+    d = torch.randn(x.shape, generator=gen) * (torch.rand(x.shape, generator=gen) < density)
+    d_thr, d_w = hip.ste_conv_backward(g(images), g(x), g(thr), g(d), stride)
+    ref_thr = -(d.double() * orc.ste_slope(x.double(), thr.double().view(1, -1, 1, 1))).sum(dim=(0, 2, 3))
+    ref_w = orc.conv_weight_grad(images.double(), d.double(), stride, weight.shape)
+    assert_close_grad(d_thr, ref_thr, "d_thr", rtol=2e-5)
+    assert_close_grad(d_w, ref_w, "d_conv_weight", rtol=2e-5)
+    again = hip.ste_conv_backward(g(images), g(x), g(thr), g(d), stride)
+    assert torch.equal(again[0], d_thr) and torch.equal(again[1], d_w)  # fixed summation order
 
 
 # ------------------------------------------------------------------------------------ classifier

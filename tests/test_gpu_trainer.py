@@ -93,3 +93,39 @@ def test_c4_shaped_step_list_and_lds_paths_agree(monkeypatch):
     assert abs(cfgs["list"][0] - cfgs["bits"][0]) <= 1e-5 * max(1.0, abs(cfgs["list"][0]))
     assert cfgs["list"][2] == cfgs["bits"][2] and cfgs["list"][2][0] > 20000  # ~28k active features per image
     assert_close_grad(cfgs["bits"][1], cfgs["list"][1], "flat gradient")
+
+
+def thresholds_for_density(model, images, density):
+    """Per-channel thresholds that leave about `density` of the conv outputs above them (SURVEY 8d's sweep)."""
+    with torch.no_grad():
+        conv = F.conv2d(images, model.conv.weight.detach().to(images.device), stride=model.conv.stride, padding=1)
+        per_channel = conv.transpose(0, 1).flatten(1)
+        return torch.quantile(per_channel, 1.0 - density, dim=1)
+
+
+@pytest.mark.parametrize("path", ("bits", "list"))
+@pytest.mark.parametrize("density", (0.01, 0.05, 0.25, 0.9))
+def test_density_sweep_step_against_oracle(monkeypatch, density, path):
+    """Whole-step gradients at about 1 %, 5 %, 25 % and 90 % active features (the sweep SURVEY 8d asks for, after the
+    reference's tests/test_model.py:570-576), both FeatureTransformer kernel families, against the CPU oracle."""
+    import nnue_oracle as orc
+    monkeypatch.setenv("NNUE_FT_PATH", path)
+    torch.manual_seed(2)
+    model = nnue.NNUE(nnue.GridFeatureSet(10, 8), 256, 32, 16, num_classes=10)
+    gen = torch.Generator().manual_seed(3)
+    images, labels = torch.randn(48, 3, 32, 32, generator=gen), torch.randint(0, 10, (48,), generator=gen)
+    with torch.no_grad():
+        model.visual_threshold.copy_(thresholds_for_density(model, images, density))
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    tr = NnueTrainer(model, 48, (32, 32), lr=0.0, use_graph=False)
+    assert tr.use_bits == (path == "bits")
+    loss = tr.step(images.to(DEV), labels.to(DEV))
+    _, ref_loss, ref_grads, keep = orc.loss_and_grads_explicit(params, images, labels, 3)
+    n_mean, n_max = tr.active_stats()
+    assert n_max == int(keep["n"].max()) and abs(n_mean - float(keep["n"].float().mean())) < 1e-3
+    assert abs(n_mean / 968 - density) < 0.3 * density + 0.01  # the sweep point is what it says
+    assert abs(float(loss) - float(ref_loss)) <= 1e-4 * max(1.0, abs(float(ref_loss)))
+    grads = tr.layout.views(tr.flat_grads)
+    for k, ref in ref_grads.items():
+        assert_close_grad(grads[k], ref, f"{k} density={density}")
