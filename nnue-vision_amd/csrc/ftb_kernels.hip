@@ -48,19 +48,21 @@ __device__ __forceinline__ void emit_tile_list(u64 m0, u64 m1, int lane, unsigne
 }
 
 // ------------------------------------------------------------------ bit masks + lists from conv_out
-// One workgroup per sample; wave w takes position tiles w, w+4, ... (128 positions = two ballots).
+// grid (sample, slice); wave w of slice y takes position tiles 4y + w, 4y + w + 4 * slices, ... (128 positions =
+// two ballots).  With more than one slice per sample (large maps: 512 tiles at 224x224) the per-sample counts are
+// integer-valued atomics into buffers the host zeroes first -- exact and order-independent.
 __global__ __launch_bounds__(256) void bits_rows_kernel(const float* __restrict__ conv_out,
                                                         const float* __restrict__ thr, int G, int P, int F,
                                                         u64* __restrict__ maskW, int pw64, float* __restrict__ sink,
                                                         int* __restrict__ n, unsigned short* __restrict__ tlW,
-                                                        unsigned char* __restrict__ tcW, int ntW) {
+                                                        unsigned char* __restrict__ tcW, int ntW, int slices) {
   __shared__ int cnt_s[4], sink_s[4];
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* __restrict__ x = conv_out + (size_t)b * P;
   const int direct = (F - 1 < P) ? F - 1 : P;  // positions with a table row of their own
   int cnt = 0, snk = 0;
-  for (int t = wave; t < pw64 / 2; t += 4) {
+  for (int t = blockIdx.y * 4 + wave; t < pw64 / 2; t += 4 * slices) {
     const int p0 = t * 128 + lane, p1 = p0 + 64;
     const bool on0 = (p0 < P) && (x[p0] > thr[p0 / G]);
     const bool on1 = (p1 < P) && (x[p1] > thr[p1 / G]);
@@ -82,8 +84,14 @@ __global__ __launch_bounds__(256) void bits_rows_kernel(const float* __restrict_
   }
   __syncthreads();
   if (tid == 0) {
-    n[b] = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3];
-    sink[b] = (float)(sink_s[0] + sink_s[1] + sink_s[2] + sink_s[3]);
+    const int total = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3], snk_total = sink_s[0] + sink_s[1] + sink_s[2] + sink_s[3];
+    if (slices == 1) {
+      n[b] = total;
+      sink[b] = (float)snk_total;
+    } else {
+      atomicAdd(&n[b], total);
+      if (snk_total) atomicAdd(&sink[b], (float)snk_total);  // small integers: exact in any order
+    }
   }
 }
 
@@ -589,9 +597,19 @@ extern "C" int nnue_binarize_bits(const float* conv_out, const float* thr, int B
   nnue_ftb_list_tiles(B, F, P, &ntf, &ntb);
   hipStream_t s = static_cast<hipStream_t>(stream);
   NNUE_REQUIRE(stages >= 1 && stages <= 3, NNUE_E_ARG, "nnue_binarize_bits: stages must be 1 (per-sample), 2 (transposed) or 3 (both)");
-  if (stages & 1)
-    hipLaunchKernelGGL(bits_rows_kernel, dim3(B), dim3(256), 0, s, conv_out, thr, Gh * Gw, P, F, reinterpret_cast<u64*>(maskW), pw64,
-                       sink, n, reinterpret_cast<unsigned short*>(tlW), tcW, ntf);
+  if (stages & 1) {
+    int slices = (pw64 / 2) / 32;  // >= 8 tiles per wave before a sample is split
+    slices = slices < 1 ? 1 : (slices > 32 ? 32 : slices);
+    if (slices > 1) {
+      if (hipMemsetAsync(n, 0, (size_t)B * sizeof(int), s) != hipSuccess || hipMemsetAsync(sink, 0, (size_t)B * sizeof(float), s) != hipSuccess) {
+        (void)hipGetLastError();
+        nnue_set_error("nnue_binarize_bits: clearing the per-sample counters failed");
+        return NNUE_E_LAUNCH;
+      }
+    }
+    hipLaunchKernelGGL(bits_rows_kernel, dim3(B, slices), dim3(256), 0, s, conv_out, thr, Gh * Gw, P, F, reinterpret_cast<u64*>(maskW), pw64,
+                       sink, n, reinterpret_cast<unsigned short*>(tlW), tcW, ntf, slices);
+  }
   if (stages & 2)
     hipLaunchKernelGGL(bits_transpose_kernel, dim3((F + 1 + kTrRows - 1) / kTrRows, ntb), dim3(256), 0, s, conv_out, thr, sink, B, Gh * Gw, P, F,
                      reinterpret_cast<u64*>(maskT), bw64, reinterpret_cast<unsigned short*>(tlT), tcT, ntb);
