@@ -41,6 +41,7 @@ WORKLOADS = {
 }
 OPT = dict(lr=0.01, momentum=0.9, weight_decay=2e-4, max_grad_norm=1.0)  # config/train_nnue.py:29-36
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA, dense (= the f32 vector rate)
 
 
 def parse():
@@ -162,8 +163,9 @@ def main():
     n_mean, n_max = trainer.active_stats()
 
     # ---- instrumented pass: per-entry-point durations from HIP events on the launch stream
-    ftp = "nnue_ftb" if trainer.use_bits else "nnue_ft"  # bit-mask/LDS-staged kernels or id-list kernels
-    names = ["nnue_conv3x3_forward", "nnue_binarize_bits" if trainer.use_bits else "nnue_binarize_features",
+    # FeatureTransformer kernel family: dense MFMA products, bit-mask/LDS-staged gather kernels or id-list kernels
+    ftp = {"mfma": "nnue_ftm", "bits": "nnue_ftb", "list": "nnue_ft"}[trainer.ft_path]
+    names = ["nnue_conv3x3_forward", {"mfma": "nnue_ftm_binarize", "bits": "nnue_binarize_bits", "list": "nnue_binarize_features"}[trainer.ft_path],
              f"{ftp}_forward", "nnue_classifier_train_step",
              f"{ftp}_backward_weight", f"{ftp}_backward_values", "nnue_ste_conv_backward", "nnue_sgd_step"]
     timers = {k: [] for k in names}
@@ -199,7 +201,9 @@ def main():
         if not files:
             return None
         kernels = json.loads(files[-1].read_text())["kernels"]
-        want = {"nnue_ftb_forward": ("ftb_gather_kernel", ", 0,"), "nnue_ftb_backward_weight": ("ftb_gather_kernel", ", 1,"),
+        want = {"nnue_ftm_forward": ("ftm_gemm_kernel", "FwdEpi"), "nnue_ftm_backward_weight": ("ftm_gemm_kernel", "BwwEpi"),
+                "nnue_ftm_backward_values": ("ftm_gemm_kernel", "ValEpi"),
+                "nnue_ftb_forward": ("ftb_gather_kernel", ", 0,"), "nnue_ftb_backward_weight": ("ftb_gather_kernel", ", 1,"),
                 "nnue_ftb_backward_values": ("ftb_values_kernel", ""), "nnue_ft_forward": ("ft_forward_wide", ""),
                 "nnue_ft_backward_weight": ("ft_backward_weight_wide", ""), "nnue_ft_backward_values": ("ft_backward_values_wide", "")}.get(entry)
         for name, v in kernels.items():
@@ -208,14 +212,28 @@ def main():
         return None
 
     dom = max(alg, key=lambda k: dur_us[k])
-    achieved = alg[dom] / (dur_us[dom] * 1e-6) / 1e9 if dur_us[dom] > 0 else 0.0
     table_mb = model.input.weight.numel() * 4 / 1e6
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": (pmc_traffic(dom) or {}).get("bytes"),
-                "traffic_detail": pmc_traffic(dom),
-                "alg_bytes_per_launch": int(alg[dom]), "avg_launch_us": round(dur_us[dom], 2),
-                "regime": ("table %.1f MB is L2/Infinity-Cache resident: algorithmic rate is cache bandwidth and may exceed the HBM peak"
-                           % table_mb) if table_mb < 200 else "table %.0f MB exceeds the Infinity Cache: HBM-bound" % table_mb}
+    alg_rate = alg[dom] / (dur_us[dom] * 1e-6) / 1e9 if dur_us[dom] > 0 else 0.0
+    if trainer.ft_path == "mfma":
+        # dense f32-MFMA products: priced in flops of the product actually executed (2 M N K, all positions, not only
+        # the active ones) against the f32 matrix peak; the SURVEY 8d algorithmic-byte rate is kept beside it
+        direct = min(trainer.F - 1, trainer.P)
+        flops = {f"{ftp}_forward": 2.0 * B * direct * cfg["l1"], f"{ftp}_backward_weight": 2.0 * B * direct * cfg["l1"],
+                 f"{ftp}_backward_values": 2.0 * B * trainer.P * cfg["l1"]}
+        achieved = flops[dom] / (dur_us[dom] * 1e-6) / 1e12 if dur_us[dom] > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": (pmc_traffic(dom) or {}).get("bytes"),
+                    "traffic_detail": pmc_traffic(dom), "flops_per_launch": int(flops[dom]), "avg_launch_us": round(dur_us[dom], 2),
+                    "alg_bytes_per_launch": int(alg[dom]), "alg_GBps": round(alg_rate, 1),
+                    "regime": "v_mfma_f32_16x16x4_f32 products over the whole map (active and inactive positions); "
+                              "table %.1f MB" % table_mb}
+    else:
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(alg_rate, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(alg_rate / HBM_PEAK_GBS, 4), "traffic": (pmc_traffic(dom) or {}).get("bytes"),
+                    "traffic_detail": pmc_traffic(dom),
+                    "alg_bytes_per_launch": int(alg[dom]), "avg_launch_us": round(dur_us[dom], 2),
+                    "regime": ("table %.1f MB is L2/Infinity-Cache resident: algorithmic rate is cache bandwidth and may exceed the HBM peak"
+                               % table_mb) if table_mb < 200 else "table %.0f MB exceeds the Infinity Cache: HBM-bound" % table_mb}
 
     if rank == 0:
         out = {

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 8
+#define NNUE_HIP_ABI_VERSION 9
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -170,6 +170,40 @@ int nnue_ftb_backward_weight(const float* d_out, const uint8_t* tlT, const uint8
 /* Its value gradient scattered to the map (autograd of nnue.py:705-707 and :628-633; identity STE :33):
  *   d_conv_out[b,p] = active(b,p) ? < d_out[b,:], weight[min(p,F-1),:] > : 0     for every p < P */
 int nnue_ftb_backward_values(const float* d_out, const float* weight, const uint64_t* maskW, int pw64,
+                             int B, int F, int P, int L1, float* d_conv_out, nnue_stream_t stream);
+
+/* ---- FeatureTransformer for binary grid features as dense products on the f32 MFMA ----------------
+ *
+ * At the reference's threshold 43 % of the grid features are active (414 of 968 at 32x32), so the products
+ *     out      = A W + bias,   d_weight = A^T d_out,   d_value = (d_out W^T) . A
+ * with A[b][f] = membership of table row f in sample b are dense enough to run as matrix products
+ * (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate; summation order differs from the gather
+ * kernels).  A is the binary map itself as a float {0,1} matrix bits[B][P] (P = fps*Gh*Gw, nnue.py:19-25);
+ * no masks or id lists are built.  sink[b] = number of active positions >= F-1 (they clamp to row F-1,
+ * nnue.py:701), a rank-one term.  P and L1 must be multiples of 4 (nnue_ftm_supported). */
+int nnue_ftm_supported(int F, int P, int L1);
+int64_t nnue_ftm_scratch(int B, int F, int P, int L1); /* bytes for nnue_ftm_forward (split-K slabs) */
+
+/* StraightThroughBinary.forward as a float matrix (nnue.py:19-25): bits[b,p] = conv_out[b,p] > thr[channel of p],
+ * n[b] = active positions (nnue.py:603-607), sink[b] as above.  Bit-exact given conv_out. */
+int nnue_ftm_binarize(const float* conv_out, const float* thr, int B, int fps, int Gh, int Gw, int F,
+                      float* bits, int32_t* n, float* sink, nnue_stream_t stream);
+
+/* FeatureTransformer.forward for the binary map (nnue.py:686-710):
+ *   out[b,:] = bias + sum_{p active, p < min(F-1,P)} weight[p,:] + sink[b] * weight[F-1,:] */
+int nnue_ftm_forward(const float* bits, const float* sink, const float* weight, const float* bias,
+                     int B, int F, int P, int L1, float* out,
+                     void* scratch, int64_t scratch_bytes, nnue_stream_t stream);
+
+/* Its weight/bias gradient (autograd of nnue.py:702-708); fixed summation order, no atomics.  Rows the map
+ * cannot reach are written as zero.  Either output may be NULL. */
+int nnue_ftm_backward_weight(const float* bits, const float* sink, const float* d_out,
+                             int B, int F, int P, int L1, float* d_weight, float* d_bias,
+                             nnue_stream_t stream);
+
+/* Its value gradient on the map (autograd of nnue.py:705-707 and :628-633; identity STE :33):
+ *   d_conv_out[b,p] = active(b,p) ? < d_out[b,:], weight[min(p,F-1),:] > : 0     for every p < P */
+int nnue_ftm_backward_values(const float* bits, const float* d_out, const float* weight,
                              int B, int F, int P, int L1, float* d_conv_out, nnue_stream_t stream);
 
 /* ---- pairwise product + SimpleClassifier -------------------------------------- */

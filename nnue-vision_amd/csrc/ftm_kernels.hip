@@ -1,0 +1,437 @@
+// FeatureTransformer for the binary grid features of NNUE.forward as dense products on the f32 MFMA.
+//
+// Inside NNUE.forward the feature values are {0,1} and, at the reference's threshold, 43 % of them are set
+// (n = 414 of 968 ids at 32x32, 28.1 k of 65.5 k at 224x224).  At that density "gather the active
+// rows" (nnue.py:694-708) does not skip enough to beat streaming every row once: the three products
+//     out      = A  W  + bias          A[b][f] = membership of table row f in sample b   (nnue.py:686-710)
+//     d_weight = A^T d_out             (autograd of nnue.py:702-708; d_bias = column sums of d_out)
+//     d_value  = (d_out W^T) . A       (autograd of nnue.py:705-707 + :628-633, masked to the active positions)
+// are genuine matrix products, so they run on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate --
+// the same arithmetic as the gather kernels, different summation order).  A is the binary map itself, written
+// once per step as a float {0,1} matrix bits[B][P] by nnue_ftm_binarize (nnue.py:19-25); no masks or id lists.
+// Ids >= F-1 clamp to row F-1 (nnue.py:701): that row's membership is the count sink[b], a rank-one term the
+// epilogues add (forward) or a separate column reduction forms (weight gradient); rows the map cannot reach get 0.
+//
+// One LDS-tiled kernel serves all three: block tile BM x BN, K tile BK, waves in a 2 x 2 grid, operands staged
+// with 16-byte loads along whichever axis is contiguous in memory:
+//   KC  source contiguous along k    -> LDS [row][k]   (stride BK+4), fragment = one ds_read_b128
+//   RC  source contiguous along rows -> LDS [k][row]   (stride BR+4), fragment = four ds_read_b32
+// both conflict-free.  K is permuted identically on both operands (a lane supplies k = 4q..4q+3 of each 16-k
+// block; MFMA step t takes element t), which a sum does not care about.  The next K tile's global loads are
+// issued right after the barrier that publishes the current one and stay in flight during its MFMAs.
+#include "common.h"
+
+#include <cstdlib>
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// Row-major matrix seen as (outer, inner): load() returns inner .. inner+3 of row `outer`, zero outside; rows past
+// `clamp` read row `clamp` (ids >= F-1 share table row F-1).  ld % 4 == 0 and a 16-byte aligned base are required.
+struct Mat {
+  const float* __restrict__ p;
+  int outer_n, inner_n, ld, clamp;
+  __device__ __forceinline__ float4 load(int outer, int inner) const {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (outer >= outer_n || inner >= inner_n) return v;
+    const float* __restrict__ s = p + (size_t)(outer < clamp ? outer : clamp) * ld + inner;
+    if (inner + 3 < inner_n) return *reinterpret_cast<const float4*>(s);
+    v.x = s[0];
+    if (inner + 1 < inner_n) v.y = s[1];
+    if (inner + 2 < inner_n) v.z = s[2];
+    return v;
+  }
+};
+
+// ---- epilogues: col(n) gives per-column values, store() places one element -------------------------------------
+struct FwdEpi {  // out = acc + bias + sink[b] * weight[F-1]   (or a split-K slab, finished by ftm_finish_kernel)
+  const float* __restrict__ bias;
+  const float* __restrict__ w_last;  // weight row F-1
+  const float* __restrict__ sink;
+  float* __restrict__ out;  // ksplit == 1: out [B][L1]; else partial [ksplit][B][L1]
+  int B, L1, ksplit;
+  __device__ __forceinline__ float2 col(int n) const { return ksplit == 1 ? make_float2(bias[n], w_last[n]) : make_float2(0.f, 0.f); }
+  __device__ __forceinline__ void store(int m, int n, float v, float2 c, int ks) const {
+    if (ksplit == 1) v += fmaf(sink[m], c.y, c.x);
+    out[((size_t)ks * B + m) * L1 + n] = v;
+  }
+};
+
+struct BwwEpi {  // d_weight rows with a position of their own
+  float* __restrict__ d_weight;
+  int L1;
+  __device__ __forceinline__ float2 col(int) const { return make_float2(0.f, 0.f); }
+  __device__ __forceinline__ void store(int m, int n, float v, float2, int) const { d_weight[(size_t)m * L1 + n] = v; }
+};
+
+struct ValEpi {  // d_conv_out = acc where the position is active, else 0
+  const float* __restrict__ bits;
+  float* __restrict__ d_conv_out;
+  int P;
+  __device__ __forceinline__ float2 col(int) const { return make_float2(0.f, 0.f); }
+  __device__ __forceinline__ void store(int m, int p, float v, float2, int) const {
+    const size_t o = (size_t)m * P + p;
+    d_conv_out[o] = bits[o] != 0.0f ? v : 0.0f;
+  }
+};
+
+template <int BM, int BN, int BK, bool AKC, bool BKC, class Epi>
+__global__ __launch_bounds__(256) void ftm_gemm_kernel(Mat ma, Mat mb, Epi epi, int M, int N, int K, int klen, int tiles_n) {
+  constexpr int LDA = (AKC ? BK : BM) + 4, LDB = (BKC ? BK : BN) + 4;
+  __shared__ __attribute__((aligned(16))) float As[(AKC ? BM : BK) * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[(BKC ? BN : BK) * LDB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
+  const int m_base = tile_m * BM, n_base = tile_n * BN;
+  const int k_lo = blockIdx.y * klen;
+  const int k_hi = (k_lo + klen < K) ? k_lo + klen : K;
+  constexpr int AG = BM * BK / 1024, BG = BN * BK / 1024;  // float4 groups per thread
+  constexpr int TM = BM / 32, TN = BN / 32;
+  // staging coordinates of float4 group i: (row, k) with the memory-contiguous axis walked by consecutive lanes
+  auto a_row = [&](int i) { const int g = tid + 256 * i; return AKC ? g / (BK / 4) : (g % (BM / 4)) * 4; };
+  auto a_k = [&](int i) { const int g = tid + 256 * i; return AKC ? (g % (BK / 4)) * 4 : g / (BM / 4); };
+  auto b_row = [&](int i) { const int g = tid + 256 * i; return BKC ? g / (BK / 4) : (g % (BN / 4)) * 4; };
+  auto b_k = [&](int i) { const int g = tid + 256 * i; return BKC ? (g % (BK / 4)) * 4 : g / (BN / 4); };
+  float4 ra[AG], rb[BG];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < AG; ++i) ra[i] = AKC ? ma.load(m_base + a_row(i), k0 + a_k(i)) : ma.load(k0 + a_k(i), m_base + a_row(i));
+#pragma unroll
+    for (int i = 0; i < BG; ++i) rb[i] = BKC ? mb.load(n_base + b_row(i), k0 + b_k(i)) : mb.load(k0 + b_k(i), n_base + b_row(i));
+  };
+  const int m0 = (wave >> 1) * (BM / 2), n0 = (wave & 1) * (BN / 2);
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  fetch(k_lo);
+  for (int k0 = k_lo; k0 < k_hi; k0 += BK) {
+#pragma unroll
+    for (int i = 0; i < AG; ++i) *reinterpret_cast<float4*>(&As[AKC ? a_row(i) * LDA + a_k(i) : a_k(i) * LDA + a_row(i)]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BG; ++i) *reinterpret_cast<float4*>(&Bs[BKC ? b_row(i) * LDB + b_k(i) : b_k(i) * LDB + b_row(i)]) = rb[i];
+    __syncthreads();
+    if (k0 + BK < k_hi) fetch(k0 + BK);
+#pragma unroll
+    for (int kb = 0; kb < BK; kb += 16) {
+      float4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int x = m0 + 16 * i + r, k = kb + 4 * q;
+        if (AKC) a[i] = *reinterpret_cast<const float4*>(&As[x * LDA + k]);
+        else a[i] = make_float4(As[k * LDA + x], As[(k + 1) * LDA + x], As[(k + 2) * LDA + x], As[(k + 3) * LDA + x]);
+      }
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        const int x = n0 + 16 * t + r, k = kb + 4 * q;
+        if (BKC) b[t] = *reinterpret_cast<const float4*>(&Bs[x * LDB + k]);
+        else b[t] = make_float4(Bs[k * LDB + x], Bs[(k + 1) * LDB + x], Bs[(k + 2) * LDB + x], Bs[(k + 3) * LDB + x]);
+      }
+      // consecutive MFMAs go to different accumulators
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int t = 0; t < TN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[t].x, acc[i][t], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int t = 0; t < TN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[t].y, acc[i][t], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int t = 0; t < TN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[t].z, acc[i][t], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int t = 0; t < TN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[t].w, acc[i][t], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // accumulator register e of lane 16 q + r holds C[row 4 q + e][col r]
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int n = n_base + n0 + 16 * t + r;
+    if (n >= N) continue;
+    const float2 c = epi.col(n);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m_base + m0 + 16 * i + 4 * q + e;
+        if (m < M) epi.store(m, n, acc[i][t][e], c, blockIdx.y);
+      }
+  }
+}
+
+// out = bias + sink[b] * weight[F-1] + sum of the split-K slabs (fixed order)
+__global__ __launch_bounds__(256) void ftm_finish_kernel(const float* __restrict__ partial, int ksplit, int64_t count4,
+                                                         const float* __restrict__ bias, const float* __restrict__ w_last,
+                                                         const float* __restrict__ sink, int L1, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count4) return;
+  const int64_t e = i * 4;
+  const int n = (int)(e % L1);
+  const float s = sink[e / L1];
+  const float4 bv = *reinterpret_cast<const float4*>(bias + n), wv = *reinterpret_cast<const float4*>(w_last + n);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < ksplit; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)k * count4 * 4 + e);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  acc.x += fmaf(s, wv.x, bv.x); acc.y += fmaf(s, wv.y, bv.y); acc.z += fmaf(s, wv.z, bv.z); acc.w += fmaf(s, wv.w, bv.w);
+  *reinterpret_cast<float4*>(out + e) = acc;
+}
+
+// The rows of the weight gradient that are not positions of the map, and the bias gradient:
+//   d_bias = sum_b d_out[b], d_weight[F-1] = sum_b sink[b] d_out[b], d_weight[direct .. F-2] = 0.
+// grid (ceil(L1 / 16), 1 + zero-fill slices); block y = 0 reduces 16 columns over the batch in sixteen fixed slices.
+__global__ __launch_bounds__(256) void ftm_tail_rows_kernel(const float* __restrict__ d_out, const float* __restrict__ sink,
+                                                            int B, int L1, int direct, int F, float* __restrict__ d_weight,
+                                                            float* __restrict__ d_bias) {
+  __shared__ float red[2][16][16];
+  const int c = threadIdx.x & 15, part = threadIdx.x >> 4;
+  const int col = blockIdx.x * 16 + c;
+  if (blockIdx.y > 0) {  // zero rows the map cannot reach
+    if (d_weight && col < L1)
+      for (int f = direct + (int)(blockIdx.y - 1) * 16 + part; f < F - 1; f += 16 * ((int)gridDim.y - 1)) d_weight[(size_t)f * L1 + col] = 0.0f;
+    return;
+  }
+  float sb = 0.f, sw = 0.f;
+  if (col < L1) {
+    const int per = (B + 15) / 16, lo = part * per, hi = lo + per < B ? lo + per : B;
+    for (int b = lo; b < hi; ++b) {
+      const float d = d_out[(size_t)b * L1 + col];
+      sb += d;
+      sw = fmaf(sink[b], d, sw);
+    }
+  }
+  red[0][part][c] = sb;
+  red[1][part][c] = sw;
+  __syncthreads();
+  if (part < 2 && col < L1) {  // part 0 -> bias row, part 1 -> table row F-1; sixteen partials in order
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red[part][i][c];
+    if (part == 0) {
+      if (d_bias) d_bias[col] = s;
+    } else if (d_weight) {
+      d_weight[(size_t)(F - 1) * L1 + col] = s;
+    }
+  }
+}
+
+// bits[b][p] = conv_out[b][p] > thr[channel] as float, n[b] = active positions, sink[b] = active positions >= F-1.
+// grid (B, slices); integer-valued atomics into host-zeroed counters when a sample is split (exact in any order).
+__global__ __launch_bounds__(256) void ftm_binarize_kernel(const float* __restrict__ conv_out, const float* __restrict__ thr,
+                                                           int P, int G, int F, int slices, float* __restrict__ bits,
+                                                           int* __restrict__ n, float* __restrict__ sink) {
+  __shared__ int cnt_s[4], sink_s[4];
+  const int b = blockIdx.x;
+  const float4* __restrict__ x4 = reinterpret_cast<const float4*>(conv_out + (size_t)b * P);
+  float4* __restrict__ o4 = reinterpret_cast<float4*>(bits + (size_t)b * P);
+  int cnt = 0, snk = 0;
+  for (int g = blockIdx.y * 256 + threadIdx.x; g < P / 4; g += 256 * slices) {
+    const float4 x = x4[g];
+    const int p = g * 4;
+    int c = p / G, rem = p - c * G;
+    float4 v;
+    v.x = x.x > thr[c] ? 1.0f : 0.0f;
+    if (++rem == G) { rem = 0; ++c; }
+    v.y = x.y > thr[c] ? 1.0f : 0.0f;
+    if (++rem == G) { rem = 0; ++c; }
+    v.z = x.z > thr[c] ? 1.0f : 0.0f;
+    if (++rem == G) { rem = 0; ++c; }
+    v.w = x.w > thr[c] ? 1.0f : 0.0f;
+    o4[g] = v;
+    cnt += (int)(v.x + v.y + v.z + v.w);
+    snk += (p >= F - 1 ? (int)v.x : 0) + (p + 1 >= F - 1 ? (int)v.y : 0) + (p + 2 >= F - 1 ? (int)v.z : 0) + (p + 3 >= F - 1 ? (int)v.w : 0);
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    cnt += __shfl_xor(cnt, s);
+    snk += __shfl_xor(snk, s);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    cnt_s[threadIdx.x >> 6] = cnt;
+    sink_s[threadIdx.x >> 6] = snk;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int total = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3], st = sink_s[0] + sink_s[1] + sink_s[2] + sink_s[3];
+    if (slices == 1) {
+      n[b] = total;
+      sink[b] = (float)st;
+    } else {
+      atomicAdd(&n[b], total);
+      if (st) atomicAdd(&sink[b], (float)st);
+    }
+  }
+}
+
+// ---- launch policy -------------------------------------------------------------------------------------------
+int env_int(const char* name, int fallback) {
+  const char* v = std::getenv(name);
+  return v && *v ? std::atoi(v) : fallback;
+}
+
+// Tile shapes (BM, BN, BK).  BK grows as the tile shrinks so that a K tile always carries >= 2048 MFMA cycles/wave.
+struct Shape {
+  int cfg;  // 0: 32x64x128   1: 64x64x64   2: 128x64x32   3: 64x128x32
+  int bm, bn, bk, tiles_m, tiles_n, ksplit, klen;
+};
+constexpr int kCfg[4][3] = {{32, 64, 128}, {64, 64, 64}, {128, 64, 32}, {64, 128, 32}};
+
+// prefer_m: the operand re-read per M tile is the big one (the table, in forward and value gradient), so take tall
+// tiles; otherwise (weight gradient: the map is re-read per N tile) take wide ones.  The largest preferred shape
+// that still gives every CU a workgroup wins; the forward of a small batch (M <= 128: one tall tile covers it, the
+// table is then read exactly once) splits K until there are about two workgroups per CU.
+Shape plan(int M, int N, int K, bool prefer_m, bool allow_split) {
+  static const int force_cfg = env_int("NNUE_FTM_CFG", -1), force_split = env_int("NNUE_FTM_KSPLIT", 0);
+  const int order_m[3] = {2, 1, 0}, order_n[3] = {3, 1, 0};
+  const int* order = prefer_m ? order_m : order_n;
+  auto tiles = [&](int c) { return (long long)((M + kCfg[c][0] - 1) / kCfg[c][0]) * ((N + kCfg[c][1] - 1) / kCfg[c][1]); };
+  int cfg = order[2];
+  for (int i = 0; i < 3; ++i)
+    if (tiles(order[i]) >= 256) { cfg = order[i]; break; }
+  const bool small_m = allow_split && M <= 128;
+  if (small_m) cfg = 2;
+  if (force_cfg >= 0 && force_cfg < 4) cfg = force_cfg;
+  Shape s;
+  s.cfg = cfg;
+  s.bm = kCfg[cfg][0]; s.bn = kCfg[cfg][1]; s.bk = kCfg[cfg][2];
+  s.tiles_m = (M + s.bm - 1) / s.bm;
+  s.tiles_n = (N + s.bn - 1) / s.bn;
+  const long long blocks = (long long)s.tiles_m * s.tiles_n;
+  const int ktiles = (K + s.bk - 1) / s.bk;
+  int split = 1;
+  if (allow_split && (small_m || force_split)) {
+    split = force_split ? force_split : (int)((512 + blocks - 1) / blocks);
+    if (split > ktiles / 4) split = ktiles / 4;  // at least four K tiles per slab
+    if (split > 64) split = 64;
+    if (split < 1) split = 1;
+  }
+  const int tiles_per = (ktiles + split - 1) / split;
+  s.klen = tiles_per * s.bk;
+  s.ksplit = (ktiles + tiles_per - 1) / tiles_per;
+  return s;
+}
+
+template <bool AKC, bool BKC, class Epi>
+void launch(hipStream_t st, const Shape& s, Mat ma, Mat mb, Epi epi, int M, int N, int K) {
+  const dim3 grid((unsigned)(s.tiles_m * s.tiles_n), (unsigned)s.ksplit);
+#define NNUE_FTM_LAUNCH(BM, BN, BK)                                                                                           \
+  hipLaunchKernelGGL((ftm_gemm_kernel<BM, BN, BK, AKC, BKC, Epi>), grid, dim3(256), 0, st, ma, mb, epi, M, N, K, s.klen, s.tiles_n)
+  switch (s.cfg) {
+    case 0: NNUE_FTM_LAUNCH(32, 64, 128); break;
+    case 1: NNUE_FTM_LAUNCH(64, 64, 64); break;
+    case 2: NNUE_FTM_LAUNCH(128, 64, 32); break;
+    default: NNUE_FTM_LAUNCH(64, 128, 32); break;
+  }
+#undef NNUE_FTM_LAUNCH
+}
+
+bool shape_ok(int B, int F, int P, int L1) {
+  return B > 0 && F > 0 && P > 0 && L1 > 0 && P < (1 << 30) && (long long)B * P < (1ll << 40) && (long long)F * L1 < (1ll << 40);
+}
+
+constexpr int kIntMax = 0x7fffffff;
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" int nnue_ftm_supported(int F, int P, int L1) {
+  // 16-byte staging along positions and along table columns
+  return F > 0 && P > 0 && P % 4 == 0 && L1 > 0 && L1 % 4 == 0;
+}
+
+extern "C" int64_t nnue_ftm_scratch(int B, int F, int P, int L1) {
+  if (B <= 0 || F <= 0 || P <= 0 || L1 <= 0) return 0;
+  const int direct = (F - 1 < P) ? F - 1 : P;
+  const Shape s = plan(B, L1, direct > 0 ? direct : 1, true, true);
+  return s.ksplit > 1 ? (int64_t)s.ksplit * B * L1 * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int nnue_ftm_binarize(const float* conv_out, const float* thr, int B, int fps, int Gh, int Gw, int F, float* bits,
+                                 int32_t* n, float* sink, nnue_stream_t stream) {
+  NNUE_REQUIRE(conv_out && thr && bits && n && sink, NNUE_E_ARG, "nnue_ftm_binarize: null pointer");
+  NNUE_REQUIRE(B > 0 && fps > 0 && Gh > 0 && Gw > 0 && F > 0 && (long long)fps * Gh * Gw < (1ll << 30), NNUE_E_ARG,
+               "nnue_ftm_binarize: B=%d fps=%d Gh=%d Gw=%d F=%d out of range", B, fps, Gh, Gw, F);
+  const int P = fps * Gh * Gw;
+  NNUE_REQUIRE(P % 4 == 0, NNUE_E_SHAPE, "nnue_ftm_binarize: P=%d must be a multiple of 4", P);
+  NNUE_REQUIRE(nnue_aligned16(conv_out) && nnue_aligned16(bits), NNUE_E_ARG, "nnue_ftm_binarize: pointers must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int slices = P / 8192;
+  slices = slices < 1 ? 1 : (slices > 32 ? 32 : slices);
+  if (slices > 1) {
+    if (hipMemsetAsync(n, 0, (size_t)B * sizeof(int), s) != hipSuccess || hipMemsetAsync(sink, 0, (size_t)B * sizeof(float), s) != hipSuccess) {
+      (void)hipGetLastError();
+      nnue_set_error("nnue_ftm_binarize: clearing the per-sample counters failed");
+      return NNUE_E_LAUNCH;
+    }
+  }
+  hipLaunchKernelGGL(ftm_binarize_kernel, dim3(B, slices), dim3(256), 0, s, conv_out, thr, P, Gh * Gw, F, slices, bits, n, sink);
+  return nnue_launch_status("nnue_ftm_binarize");
+}
+
+extern "C" int nnue_ftm_forward(const float* bits, const float* sink, const float* weight, const float* bias, int B, int F, int P,
+                                int L1, float* out, void* scratch, int64_t scratch_bytes, nnue_stream_t stream) {
+  NNUE_REQUIRE(bits && sink && weight && bias && out, NNUE_E_ARG, "nnue_ftm_forward: null pointer");
+  NNUE_REQUIRE(shape_ok(B, F, P, L1), NNUE_E_ARG, "nnue_ftm_forward: B=%d F=%d P=%d L1=%d out of range", B, F, P, L1);
+  NNUE_REQUIRE(nnue_ftm_supported(F, P, L1), NNUE_E_SHAPE, "nnue_ftm_forward: P=%d and L1=%d must be multiples of 4", P, L1);
+  NNUE_REQUIRE(nnue_aligned16(bits) && nnue_aligned16(weight) && nnue_aligned16(bias) && nnue_aligned16(out), NNUE_E_ARG,
+               "nnue_ftm_forward: pointers must be 16-byte aligned");
+  const int direct = (F - 1 < P) ? F - 1 : P;
+  const int K = direct > 0 ? direct : 1;  // F == 1: only the sink row; the product runs over one zero column
+  const Shape s = plan(B, L1, K, true, true);
+  const int64_t need = s.ksplit > 1 ? (int64_t)s.ksplit * B * L1 * (int64_t)sizeof(float) : 0;
+  NNUE_REQUIRE(scratch_bytes >= need && (need == 0 || (scratch && nnue_aligned16(scratch))), NNUE_E_SCRATCH,
+               "nnue_ftm_forward: scratch %lld < %lld bytes", (long long)scratch_bytes, (long long)need);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* dst = s.ksplit > 1 ? static_cast<float*>(scratch) : out;
+  const float* w_last = weight + (size_t)(F - 1) * L1;
+  launch<true, false>(st, s, Mat{bits, B, direct, P, kIntMax}, Mat{weight, direct, L1, L1, kIntMax},
+                      FwdEpi{bias, w_last, sink, dst, B, L1, s.ksplit}, B, L1, K);
+  if (s.ksplit > 1) {
+    const int64_t count4 = (int64_t)B * L1 / 4;
+    hipLaunchKernelGGL(ftm_finish_kernel, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, st, dst, s.ksplit, count4, bias, w_last, sink,
+                       L1, out);
+  }
+  return nnue_launch_status("nnue_ftm_forward");
+}
+
+extern "C" int nnue_ftm_backward_weight(const float* bits, const float* sink, const float* d_out, int B, int F, int P, int L1,
+                                        float* d_weight, float* d_bias, nnue_stream_t stream) {
+  NNUE_REQUIRE(bits && sink && d_out, NNUE_E_ARG, "nnue_ftm_backward_weight: null pointer");
+  NNUE_REQUIRE(d_weight || d_bias, NNUE_E_ARG, "nnue_ftm_backward_weight: both outputs are null");
+  NNUE_REQUIRE(shape_ok(B, F, P, L1), NNUE_E_ARG, "nnue_ftm_backward_weight: B=%d F=%d P=%d L1=%d out of range", B, F, P, L1);
+  NNUE_REQUIRE(nnue_ftm_supported(F, P, L1), NNUE_E_SHAPE, "nnue_ftm_backward_weight: P=%d and L1=%d must be multiples of 4", P, L1);
+  NNUE_REQUIRE(nnue_aligned16(bits) && nnue_aligned16(d_out), NNUE_E_ARG, "nnue_ftm_backward_weight: pointers must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int direct = (F - 1 < P) ? F - 1 : P;
+  if (d_weight && direct > 0) {
+    const Shape s = plan(direct, L1, B, false, false);
+    launch<false, false>(st, s, Mat{bits, B, direct, P, kIntMax}, Mat{d_out, B, L1, L1, kIntMax}, BwwEpi{d_weight, L1}, direct, L1, B);
+  }
+  int zero_slices = (F - 1 - direct + 255) / 256;
+  zero_slices = zero_slices > 256 ? 256 : zero_slices;
+  hipLaunchKernelGGL(ftm_tail_rows_kernel, dim3((L1 + 15) / 16, 1 + (d_weight ? zero_slices : 0)), dim3(256), 0, st, d_out, sink, B, L1, direct, F,
+                     d_weight, d_bias);
+  return nnue_launch_status("nnue_ftm_backward_weight");
+}
+
+extern "C" int nnue_ftm_backward_values(const float* bits, const float* d_out, const float* weight, int B, int F, int P, int L1,
+                                        float* d_conv_out, nnue_stream_t stream) {
+  NNUE_REQUIRE(bits && d_out && weight && d_conv_out, NNUE_E_ARG, "nnue_ftm_backward_values: null pointer");
+  NNUE_REQUIRE(shape_ok(B, F, P, L1), NNUE_E_ARG, "nnue_ftm_backward_values: B=%d F=%d P=%d L1=%d out of range", B, F, P, L1);
+  NNUE_REQUIRE(nnue_ftm_supported(F, P, L1), NNUE_E_SHAPE, "nnue_ftm_backward_values: P=%d and L1=%d must be multiples of 4", P, L1);
+  NNUE_REQUIRE(nnue_aligned16(d_out) && nnue_aligned16(weight), NNUE_E_ARG, "nnue_ftm_backward_values: pointers must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const Shape s = plan(B, P, L1, true, false);
+  launch<true, true>(st, s, Mat{d_out, B, L1, L1, kIntMax}, Mat{weight, P, L1, L1, F - 1}, ValEpi{bits, d_conv_out, P}, B, P, L1);
+  return nnue_launch_status("nnue_ftm_backward_values");
+}

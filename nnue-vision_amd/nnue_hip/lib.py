@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -45,6 +45,12 @@ SIGNATURES = {
     "nnue_ftb_backward_weight": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p,
                                           _c_p, _c_i64, _c_p]),
     "nnue_ftb_backward_values": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p]),
+    "nnue_ftm_supported": (_c_int, [_c_int, _c_int, _c_int]),
+    "nnue_ftm_scratch": (_c_i64, [_c_int, _c_int, _c_int, _c_int]),
+    "nnue_ftm_binarize": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p]),
+    "nnue_ftm_forward": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_i64, _c_p]),
+    "nnue_ftm_backward_weight": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
+    "nnue_ftm_backward_values": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p]),
     "nnue_classifier_scratch": (_c_i64, [_c_int, _c_int, _c_int, _c_int]),
     "nnue_classifier_forward": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_f,
                                          _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p,
@@ -367,16 +373,27 @@ def ftb_supported(l1: int) -> bool:
     return bool(load().nnue_ftb_supported(int(l1)))
 
 
-def use_bit_path(num_rows: int, l1: int) -> bool:
-    """Which FeatureTransformer kernels the fused path uses for binary features.
+def ft_path(num_rows: int, positions: int, l1: int) -> str:
+    """Which FeatureTransformer kernels the fused path uses for the binary map: "mfma" | "bits" | "list".
 
-    "list" = id-list gather kernels (every sample gathers its rows from L2); "bits" = tile-list kernels that
-    stage table tiles in LDS once per sample tile (memory-side traffic drops by the tile factor).
-    NNUE_FT_PATH=list|bits forces one; the default takes the LDS-staged kernels whenever the width allows."""
+    "mfma" = dense f32-MFMA products over the float {0,1} map (fastest at the reference's ~43 % density and still
+    ahead at 1 %); "bits" = tile-list kernels that stage table tiles in LDS once per sample tile; "list" = id-list
+    gather kernels (any shape).  NNUE_FT_PATH=mfma|bits|list forces one where the shape allows it; the default
+    takes the first of mfma, bits, list that supports the shape."""
     mode = os.environ.get("NNUE_FT_PATH", "auto")
-    if mode == "list" or not ftb_supported(l1):
-        return False
-    return True
+    can_mfma, can_bits = ftm_supported(num_rows, positions, l1), ftb_supported(l1)
+    if mode == "list":
+        return "list"
+    if mode == "bits":
+        return "bits" if can_bits else "list"
+    if can_mfma:
+        return "mfma"
+    return "bits" if can_bits else "list"
+
+
+def use_bit_path(num_rows: int, l1: int) -> bool:
+    """True when the LDS-staged tile-list kernels are allowed for this width (see ft_path)."""
+    return os.environ.get("NNUE_FT_PATH", "auto") != "list" and ftb_supported(l1)
 
 
 def binarize_bits(conv_out: torch.Tensor, thr: torch.Tensor, num_rows: int, l1: int,
@@ -439,6 +456,100 @@ def ftb_backward_values(d_out: torch.Tensor, weight: torch.Tensor, bits: Feature
         raise ValueError("ftb_backward_values: dst has the wrong size")
     _call("nnue_ftb_backward_values", d_out.data_ptr(), weight.data_ptr(), bits.maskW.data_ptr(), bits.maskW.shape[1],
           b, bits.num_rows, bits.positions, l1, dst.data_ptr(), _stream(d_out))
+    return dst
+
+
+# ---------------------------------------------------------------------------- FeatureTransformer, dense MFMA form
+def ftm_supported(num_rows: int, positions: int, l1: int) -> bool:
+    return bool(load().nnue_ftm_supported(int(num_rows), int(positions), int(l1)))
+
+
+def ftm_scratch_bytes(b: int, num_rows: int, positions: int, l1: int) -> int:
+    return int(load().nnue_ftm_scratch(int(b), int(num_rows), int(positions), int(l1)))
+
+
+class FeatureMatrix:
+    """The binary map of one batch as a float {0,1} matrix (layout: include/nnue_hip.h, nnue_ftm_*)."""
+    bits: torch.Tensor     # float32 [B, P]
+    n: torch.Tensor        # int32 [B]    active positions
+    sink: torch.Tensor     # float32 [B]  active positions >= F-1
+    scratch: torch.Tensor  # uint8, split-K slabs of the forward
+    positions: int
+    num_rows: int
+
+    def __init__(self, bits, n, sink, scratch, positions, num_rows):
+        self.bits, self.n, self.sink, self.scratch, self.positions, self.num_rows = bits, n, sink, scratch, positions, num_rows
+
+    @property
+    def batch(self) -> int:
+        return self.n.shape[0]
+
+    @staticmethod
+    def empty(batch: int, positions: int, num_rows: int, l1: int, device) -> "FeatureMatrix":
+        return FeatureMatrix(torch.empty((batch, positions), dtype=torch.float32, device=device),
+                             torch.empty((batch,), dtype=torch.int32, device=device),
+                             torch.empty((batch,), dtype=torch.float32, device=device),
+                             torch.empty((max(16, ftm_scratch_bytes(batch, num_rows, positions, l1)),), dtype=torch.uint8, device=device),
+                             positions, num_rows)
+
+
+def ftm_binarize(conv_out: torch.Tensor, thr: torch.Tensor, num_rows: int, l1: int,
+                 fm: Optional[FeatureMatrix] = None) -> FeatureMatrix:
+    conv_out = _need(conv_out, torch.float32, "conv_out")
+    if conv_out.dim() != 4:
+        raise ValueError(f"conv_out: expected [B,fps,Gh,Gw], got {tuple(conv_out.shape)}")
+    b, fps, gh, gw = conv_out.shape
+    thr = _need(thr.reshape(-1), torch.float32, "threshold", (fps,))
+    if fm is None:
+        fm = FeatureMatrix.empty(b, fps * gh * gw, num_rows, l1, conv_out.device)
+    elif fm.batch != b or fm.positions != fps * gh * gw or fm.num_rows != num_rows:
+        raise ValueError("ftm_binarize: buffers do not match the map")
+    _call("nnue_ftm_binarize", conv_out.data_ptr(), thr.data_ptr(), b, fps, gh, gw, int(num_rows), fm.bits.data_ptr(),
+          fm.n.data_ptr(), fm.sink.data_ptr(), _stream(conv_out))
+    return fm
+
+
+def ftm_forward(weight: torch.Tensor, bias: torch.Tensor, fm: FeatureMatrix, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    weight = _need(weight, torch.float32, "input.weight")
+    f, l1 = weight.shape
+    bias = _need(bias, torch.float32, "input.bias", (l1,))
+    if f != fm.num_rows:
+        raise ValueError("ftm_forward: the map was built for a different table")
+    if out is None:
+        out = torch.empty((fm.batch, l1), dtype=torch.float32, device=weight.device)
+    _call("nnue_ftm_forward", fm.bits.data_ptr(), fm.sink.data_ptr(), weight.data_ptr(), bias.data_ptr(), fm.batch, f,
+          fm.positions, l1, out.data_ptr(), fm.scratch.data_ptr(), fm.scratch.numel(), _stream(weight))
+    return out
+
+
+def ftm_backward_weight(d_out: torch.Tensor, fm: FeatureMatrix, d_weight: Optional[torch.Tensor] = None,
+                        d_bias: Optional[torch.Tensor] = None, want_weight: bool = True, want_bias: bool = True):
+    d_out = _need(d_out, torch.float32, "d_out")
+    if d_out.dim() != 2 or d_out.shape[0] != fm.batch:
+        raise ValueError("ftm_backward_weight: d_out does not match the map")
+    l1 = d_out.shape[1]
+    if want_weight and d_weight is None:
+        d_weight = torch.empty((fm.num_rows, l1), dtype=torch.float32, device=d_out.device)
+    if want_bias and d_bias is None:
+        d_bias = torch.empty((l1,), dtype=torch.float32, device=d_out.device)
+    _call("nnue_ftm_backward_weight", fm.bits.data_ptr(), fm.sink.data_ptr(), d_out.data_ptr(), fm.batch, fm.num_rows,
+          fm.positions, l1, _ptr(d_weight if want_weight else None), _ptr(d_bias if want_bias else None), _stream(d_out))
+    return d_weight, d_bias
+
+
+def ftm_backward_values(d_out: torch.Tensor, weight: torch.Tensor, fm: FeatureMatrix,
+                        dst: Optional[torch.Tensor] = None) -> torch.Tensor:
+    d_out = _need(d_out, torch.float32, "d_out")
+    weight = _need(weight, torch.float32, "input.weight")
+    b, l1 = d_out.shape
+    if tuple(weight.shape) != (fm.num_rows, l1) or b != fm.batch:
+        raise ValueError("ftm_backward_values: shape mismatch")
+    if dst is None:
+        dst = torch.empty((b, fm.positions), dtype=torch.float32, device=d_out.device)
+    elif dst.numel() != b * fm.positions:
+        raise ValueError("ftm_backward_values: dst has the wrong size")
+    _call("nnue_ftm_backward_values", fm.bits.data_ptr(), d_out.data_ptr(), weight.data_ptr(), b, fm.num_rows, fm.positions,
+          l1, dst.data_ptr(), _stream(d_out))
     return dst
 
 

@@ -62,9 +62,12 @@ class NnueFn(torch.autograd.Function):
     def forward(ctx, images, thr, conv_w, ft_w, ft_b, w1, b1, w2, b2, w3, b3, stride, clip):
         images = images.contiguous()
         conv_out = lib.conv3x3_forward(images, conv_w, stride)
-        # binary features: bit masks + LDS-staged tiles when the width allows, id lists otherwise
-        ctx.use_bits = lib.use_bit_path(ft_w.shape[0], ft_w.shape[1])
-        if ctx.use_bits:
+        # binary features: dense MFMA products over the float map, else bit masks + LDS-staged tiles, else id lists
+        ctx.path = lib.ft_path(ft_w.shape[0], conv_out[0].numel(), ft_w.shape[1])
+        if ctx.path == "mfma":
+            feats = lib.ftm_binarize(conv_out, thr, ft_w.shape[0], ft_w.shape[1])
+            ft = lib.ftm_forward(ft_w, ft_b, feats)
+        elif ctx.path == "bits":
             feats = lib.binarize_bits(conv_out, thr, ft_w.shape[0], ft_w.shape[1])
             ft = lib.ftb_forward(ft_w, ft_b, feats)
         else:
@@ -83,13 +86,17 @@ class NnueFn(torch.autograd.Function):
         d_ft, g_cls = lib.classifier_backward(ft, True, w1, w2, w3, h1, h2, d_logits.contiguous(), ctx.clip)
         d_ftw = d_ftb = d_thr = d_conv_w = d_images = None
         if need[3] or need[4]:
-            if ctx.use_bits:
+            if ctx.path == "mfma":
+                d_ftw, d_ftb = lib.ftm_backward_weight(d_ft, feats, want_weight=need[3], want_bias=need[4])
+            elif ctx.path == "bits":
                 d_ftw, d_ftb = lib.ftb_backward_weight(d_ft, feats, want_weight=need[3], want_bias=need[4])
             else:
                 d_ftw, d_ftb = lib.ft_backward_weight(d_ft, feats, ft_w.shape[0], want_weight=need[3], want_bias=need[4])
         if need[0] or need[1] or need[2]:
             # value gradient of the binary features == d(conv_out) (identity STE, nnue.py:33)
-            if ctx.use_bits:
+            if ctx.path == "mfma":
+                d_conv_out = lib.ftm_backward_values(d_ft, ft_w, feats).view_as(conv_out)
+            elif ctx.path == "bits":
                 d_conv_out = lib.ftb_backward_values(d_ft, ft_w, feats).view_as(conv_out)
             else:
                 d_conv_out = lib.ft_backward_values(d_ft, ft_w, feats, feats.cap).view_as(conv_out)

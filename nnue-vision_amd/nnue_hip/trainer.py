@@ -162,10 +162,13 @@ class NnueTrainer:
                        for _ in range(max(1, input_slots))]
         self.images, self.labels = self.inputs[0]
         self.conv_out = torch.empty((B, self.fps, self.gh, self.gw), **f32)
-        # binary features: bit masks + LDS-staged FT kernels when the width allows, id lists otherwise
-        self.use_bits = lib.use_bit_path(self.F, self.L1)
+        # binary features: float {0,1} map + dense MFMA products when the shape allows, else bit masks + LDS-staged
+        # gather kernels, else id lists
+        self.ft_path = lib.ft_path(self.F, self.P, self.L1)
+        self.use_mfma, self.use_bits = self.ft_path == "mfma", self.ft_path == "bits"
+        self.fm = lib.FeatureMatrix.empty(B, self.P, self.F, self.L1, self.dev) if self.use_mfma else None
         self.bits = lib.FeatureBits.empty(B, self.P, self.F, self.L1, self.dev) if self.use_bits else None
-        self.act = None if self.use_bits else lib.ActList.empty(B, self.P, self.F, self.dev)
+        self.act = lib.ActList.empty(B, self.P, self.F, self.dev) if self.ft_path == "list" else None
         self.ft = torch.empty((B, self.L1), **f32)
         self.h1 = torch.empty((B, self.L2), **f32)
         self.h2 = torch.empty((B, self.L3), **f32)
@@ -219,7 +222,9 @@ class NnueTrainer:
         p, g = self.p, self.g
         if name == "front":
             lib.conv3x3_forward(self.images, p["conv.weight"], self.stride, out=self.conv_out)
-            if self.use_bits:
+            if self.use_mfma:
+                lib.ftm_binarize(self.conv_out, p["visual_threshold"], self.F, self.L1, fm=self.fm)
+            elif self.use_bits:
                 lib.binarize_bits(self.conv_out, p["visual_threshold"], self.F, self.L1, bits=self.bits, stages=1)
             else:
                 lib.binarize_features(self.conv_out, p["visual_threshold"], self.F, act=self.act)
@@ -227,20 +232,26 @@ class NnueTrainer:
             if self.use_bits:
                 lib.binarize_bits(self.conv_out, p["visual_threshold"], self.F, self.L1, bits=self.bits, stages=2)
         elif name == "forward":
-            if self.use_bits:
+            if self.use_mfma:
+                lib.ftm_forward(p["input.weight"], p["input.bias"], self.fm, out=self.ft)
+            elif self.use_bits:
                 lib.ftb_forward(p["input.weight"], p["input.bias"], self.bits, out=self.ft)
             else:
                 lib.ft_forward(p["input.weight"], p["input.bias"], self.act, out=self.ft)
             self._cls_step(1)
         elif name == "ft_wgrad":
-            if self.use_bits:
+            if self.use_mfma:
+                lib.ftm_backward_weight(self.d_ft, self.fm, d_weight=g["input.weight"], d_bias=g["input.bias"])
+            elif self.use_bits:
                 lib.ftb_backward_weight(self.d_ft, self.bits, d_weight=g["input.weight"], d_bias=g["input.bias"])
             else:
                 lib.ft_backward_weight(self.d_ft, self.act, self.F, d_weight=g["input.weight"], d_bias=g["input.bias"])
         elif name == "cls_wgrad":
             self._cls_step(2)
         elif name == "tail":
-            if self.use_bits:
+            if self.use_mfma:
+                lib.ftm_backward_values(self.d_ft, p["input.weight"], self.fm, dst=self.d_conv_out)
+            elif self.use_bits:
                 lib.ftb_backward_values(self.d_ft, p["input.weight"], self.bits, dst=self.d_conv_out)
             else:
                 lib.ft_backward_values(self.d_ft, p["input.weight"], self.act, self.P, dst=self.d_conv_out)
@@ -455,5 +466,5 @@ class NnueTrainer:
 
     def active_stats(self) -> Tuple[float, int]:
         """(mean, max) active features per image of the last batch -- reads back; not for timed regions."""
-        n = (self.bits if self.use_bits else self.act).n.float()
+        n = (self.fm if self.use_mfma else self.bits if self.use_bits else self.act).n.float()
         return float(n.mean()), int(n.max())

@@ -1,0 +1,133 @@
+"""FeatureTransformer for the binary map as dense f32-MFMA products (nnue_ftm_*): parity with the float64
+restatement of the reference formula (nnue.py:686-710 and its autograd), with the gather kernels, and through the
+golden model fixtures.  ``-m gpu``."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import nnue_oracle as orc
+from conftest import MODEL_CASES, assert_close_grad, assert_close_logits, golden_model
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from nnue_hip import lib
+    lib.load()
+    return lib
+
+
+def dense_reference(conv_out, thr, weight, bias, d_out):
+    """float64: A (membership incl. the clamp sink), out, d_weight, d_bias, d_conv_out."""
+    b, fps, gh, gw = conv_out.shape
+    p, (f, l1) = fps * gh * gw, weight.shape
+    bits = (conv_out > thr.view(1, -1, 1, 1)).double().reshape(b, p)
+    rows = torch.clamp(torch.arange(p), max=f - 1)
+    a = torch.zeros(b, f, dtype=torch.float64)
+    a.index_add_(1, rows, bits)  # positions >= F-1 pile up on row F-1
+    w, d = weight.double(), d_out.double()
+    out = a @ w + bias.double()
+    d_w, d_b = a.t() @ d, d.sum(0)
+    d_val = (d @ w.t())[:, rows] * bits
+    n = bits.sum(1).to(torch.int32)
+    sink = bits[:, f - 1:].sum(1).float() if p >= f else torch.zeros(b)
+    return out, d_w, d_b, d_val.reshape(conv_out.shape), n, sink
+
+
+SHAPES = [  # B, fps, Gh, Gw, F, L1: the CIFAR map (clamp sink), exact-fit map, table larger than the map, ragged everything
+    (512, 8, 11, 11, 800, 1024), (64, 8, 11, 11, 800, 256), (37, 4, 8, 8, 256, 64), (5, 4, 3, 3, 100, 36),
+    (16, 64, 8, 8, 4096, 128), (3, 2, 2, 1, 3, 4), (130, 8, 10, 10, 800, 200), (33, 12, 5, 5, 150, 72), (1, 4, 1, 1, 4, 8),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("density", (0.02, 0.45, 1.0))
+def test_ftm_kernels_against_float64(hip, shape, density):
+    b, fps, gh, gw, f, l1 = shape
+    assert hip.ftm_supported(f, fps * gh * gw, l1)
+    gen = torch.Generator().manual_seed(b * 7 + f)
+    conv_out = torch.randn(b, fps, gh, gw, generator=gen)
+    thr = torch.quantile(conv_out.transpose(0, 1).flatten(1), 1.0 - density, dim=1) if density < 1.0 else torch.full((fps,), -1e9)
+    weight, bias = torch.randn(f, l1, generator=gen) * 0.1, torch.randn(l1, generator=gen)
+    d_out = torch.randn(b, l1, generator=gen) / b
+    ref_out, ref_dw, ref_db, ref_dval, ref_n, ref_sink = dense_reference(conv_out, thr, weight, bias, d_out)
+    g = lambda t: t.to(DEV)
+    fm = hip.ftm_binarize(g(conv_out), g(thr), f, l1)
+    active = (conv_out > thr.view(1, -1, 1, 1)).reshape(b, -1)
+    assert torch.equal(fm.n.cpu(), ref_n) and torch.equal(fm.sink.cpu(), ref_sink) and torch.equal(fm.bits.cpu(), active.float())
+    out = hip.ftm_forward(g(weight), g(bias), fm)
+    assert_close_logits(out, ref_out, "out", rtol=2e-5)
+    d_w, d_b = hip.ftm_backward_weight(g(d_out), fm)
+    assert_close_grad(d_w, ref_dw, "d_weight", rtol=2e-5)
+    assert_close_grad(d_b, ref_db, "d_bias", rtol=2e-5)
+    assert not bool(d_w[min(f - 1, fps * gh * gw):f - 1].any())  # rows the map cannot reach
+    d_val = hip.ftm_backward_values(g(d_out), g(weight), fm)
+    assert_close_grad(d_val.view(conv_out.shape), ref_dval, "d_conv_out", rtol=2e-5)
+    assert not bool(d_val.view(b, -1)[~active.to(DEV)].any())  # exact zeros where inactive
+    # fixed summation order: bitwise reproducible
+    assert torch.equal(hip.ftm_forward(g(weight), g(bias), fm), out)
+    assert torch.equal(hip.ftm_backward_weight(g(d_out), fm)[0], d_w)
+    # only one output requested
+    only_b = hip.ftm_backward_weight(g(d_out), fm, want_weight=False)
+    assert only_b[0] is None and torch.equal(only_b[1], d_b)
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_ftm_on_golden_models(hip, name):
+    """The reference's own tensors: conv_out -> ft, and the input.weight / input.bias gradients of a real backward."""
+    cfg, params, grads, data = golden_model(name)
+    conv_out, thr = data["conv_out"], params["visual_threshold"]
+    w, bias = params["input.weight"], params["input.bias"]
+    f, l1 = w.shape
+    p = conv_out[0].numel()
+    if not hip.ftm_supported(f, p, l1):
+        pytest.skip(f"P={p} / L1={l1} not multiples of 4")
+    g = lambda t: t.to(DEV)
+    fm = hip.ftm_binarize(g(conv_out), g(thr), f, l1)
+    assert torch.equal(fm.n.cpu().long(), (data["idx"] >= 0).sum(1))
+    out = hip.ftm_forward(g(w), g(bias), fm)
+    assert_close_logits(out, data["ft"], "ft")
+    # upstream gradient of the reference run, recomputed by the oracle's classifier backward
+    _, _, _, keep = orc.loss_and_grads_explicit(params, data["images"], data["labels"], cfg["stride"])
+    d_w, d_b = hip.ftm_backward_weight(g(keep["d_ft"]), fm)
+    assert_close_grad(d_w, grads["input.weight"], "input.weight.grad")
+    assert_close_grad(d_b, grads["input.bias"], "input.bias.grad")
+
+
+def test_ftm_equals_gather_kernels_at_c4_shape(hip):
+    """224x224 shape (65 536-row table, 32x32x64 map): MFMA products vs the LDS-staged gather kernels."""
+    gen = torch.Generator().manual_seed(5)
+    b, fps, gh, gw, f, l1 = 8, 64, 32, 32, 65536, 1024
+    conv_out = torch.randn(b, fps, gh, gw, generator=gen).to(DEV)
+    thr = torch.full((fps,), 0.17).to(DEV)
+    weight, bias = (torch.randn(f, l1, generator=gen) * 0.1).to(DEV), torch.randn(l1, generator=gen).to(DEV)
+    d_out = (torch.randn(b, l1, generator=gen) / b).to(DEV)
+    bits = hip.binarize_bits(conv_out, thr, f, l1)
+    fm = hip.ftm_binarize(conv_out, thr, f, l1)
+    assert torch.equal(fm.n, bits.n) and torch.equal(fm.sink, bits.sink)
+    out_g, out_m = hip.ftb_forward(weight, bias, bits), hip.ftm_forward(weight, bias, fm)
+    assert float((out_g - out_m).abs().max()) <= 1e-3 * float(out_g.abs().max())  # 28 k fp32 terms, two summation orders
+    ref = (conv_out.reshape(b, -1)[:2] > 0.17).double() @ weight.double() + bias.double()
+    assert float((out_m[:2].double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    dw_g, db_g = hip.ftb_backward_weight(d_out, bits)
+    dw_m, db_m = hip.ftm_backward_weight(d_out, fm)
+    assert_close_grad(dw_m, dw_g, "d_weight", rtol=2e-5)
+    assert_close_grad(db_m, db_g, "d_bias", rtol=2e-5)
+    dv_g, dv_m = hip.ftb_backward_values(d_out, weight, bits), hip.ftm_backward_values(d_out, weight, fm)
+    assert_close_grad(dv_m, dv_g, "d_conv_out", rtol=2e-5)
+
+
+def test_ftm_argument_errors(hip):
+    conv_out, thr = torch.randn(2, 3, 3, 3, device=DEV), torch.zeros(3, device=DEV)  # P = 27: not a multiple of 4
+    assert not hip.ftm_supported(27, 27, 8)
+    with pytest.raises(hip.NnueHipError, match="multiple of 4"):
+        hip.ftm_binarize(conv_out, thr, 27, 8)
+    fm = hip.ftm_binarize(torch.randn(2, 4, 3, 3, device=DEV), torch.zeros(4, device=DEV), 36, 8)
+    with pytest.raises(ValueError):
+        hip.ftm_forward(torch.zeros(35, 8, device=DEV), torch.zeros(8, device=DEV), fm)
+    with pytest.raises(ValueError):
+        hip.ftm_backward_values(torch.zeros(3, 8, device=DEV), torch.zeros(36, 8, device=DEV), fm)
+    with pytest.raises(hip.NnueHipError):
+        hip.ftm_binarize(conv_out.cpu(), thr.cpu(), 27, 8)
