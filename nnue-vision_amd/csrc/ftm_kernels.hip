@@ -14,7 +14,7 @@
 //
 // One LDS-tiled kernel serves all three: block tile BM x BN, K tile BK, waves in a 2 x 2 grid, operands staged
 // with 16-byte loads along whichever axis is contiguous in memory:
-//   KC  source contiguous along k    -> LDS [row][k]   (stride BK+4), fragment = one ds_read_b128
+//   KC  source contiguous along k    -> LDS [row][k]   (16-byte chunks XOR-swizzled by row), fragment = one ds_read_b128
 //   RC  source contiguous along rows -> LDS [k][row]   (stride BR+4), fragment = four ds_read_b32
 // both conflict-free.  K is permuted identically on both operands (a lane supplies k = 4q..4q+3 of each 16-k
 // block; MFMA step t takes element t), which a sum does not care about.  The next K tile's global loads are
@@ -27,24 +27,28 @@ namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-// Row-major matrix seen as (outer, inner): load() returns inner .. inner+3 of row `outer`, zero outside; rows past
-// `clamp` read row `clamp` (ids >= F-1 share table row F-1).  ld % 4 == 0 and a 16-byte aligned base are required.
+// Row-major matrix seen as (outer, inner), read through a buffer descriptor: 16-byte loads at (outer, inner..inner+3),
+// hardware range check instead of branches -- rows past the end of the `bytes` window read as zero (that is how K
+// and M tails along the outer index vanish).  Rows past `clamp` read row `clamp` (ids >= F-1 share table row F-1);
+// along the inner index a K tail is zeroed by `inner_k` (KC operands whose partner is not zero there).  What a tile
+// reads past N or M along the inner index is real neighbouring data; those outputs are never stored.
 struct Mat {
-  const float* __restrict__ p;
-  int outer_n, inner_n, ld, clamp;
-  __device__ __forceinline__ float4 load(int outer, int inner) const {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (outer >= outer_n || inner >= inner_n) return v;
-    const float* __restrict__ s = p + (size_t)(outer < clamp ? outer : clamp) * ld + inner;
-    if (inner + 3 < inner_n) return *reinterpret_cast<const float4*>(s);
-    v.x = s[0];
-    if (inner + 1 < inner_n) v.y = s[1];
-    if (inner + 2 < inner_n) v.z = s[2];
-    return v;
-  }
+  const float* p;
+  unsigned bytes;  // window of valid rows, in bytes (< 2^31)
+  int ld, clamp, inner_k;
 };
+using u32x4 = __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned;
 
-// ---- epilogues: col(n) gives per-column values, store() places one element -------------------------------------
+__device__ __forceinline__ float4 mat_load(__amdgpu_buffer_rsrc_t rsrc, const Mat& m, int outer, int inner) {
+  const int row = outer < m.clamp ? outer : m.clamp;
+  // the K-tail mask moves the offset out of the window (the range check then returns zeros): nothing touches the
+  // loaded registers before the LDS store, so the load stays in flight across the MFMA phase
+  const int off = inner < m.inner_k ? (row * m.ld + inner) * 4 : 0x7ffffff0;
+  const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+  return make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]), __uint_as_float(raw[3]));
+}
+
+// ---- epilogues: col(n) gives per-column values, pre(m, n) a per-element operand loaded before any store ---------
 struct FwdEpi {  // out = acc + bias + sink[b] * weight[F-1]   (or a split-K slab, finished by ftm_finish_kernel)
   const float* __restrict__ bias;
   const float* __restrict__ w_last;  // weight row F-1
@@ -52,8 +56,9 @@ struct FwdEpi {  // out = acc + bias + sink[b] * weight[F-1]   (or a split-K sla
   float* __restrict__ out;  // ksplit == 1: out [B][L1]; else partial [ksplit][B][L1]
   int B, L1, ksplit;
   __device__ __forceinline__ float2 col(int n) const { return ksplit == 1 ? make_float2(bias[n], w_last[n]) : make_float2(0.f, 0.f); }
-  __device__ __forceinline__ void store(int m, int n, float v, float2 c, int ks) const {
-    if (ksplit == 1) v += fmaf(sink[m], c.y, c.x);
+  __device__ __forceinline__ float pre(int m, int) const { return ksplit == 1 ? sink[m] : 0.0f; }
+  __device__ __forceinline__ void store(int m, int n, float v, float2 c, float s, int ks) const {
+    if (ksplit == 1) v += fmaf(s, c.y, c.x);
     out[((size_t)ks * B + m) * L1 + n] = v;
   }
 };
@@ -62,7 +67,8 @@ struct BwwEpi {  // d_weight rows with a position of their own
   float* __restrict__ d_weight;
   int L1;
   __device__ __forceinline__ float2 col(int) const { return make_float2(0.f, 0.f); }
-  __device__ __forceinline__ void store(int m, int n, float v, float2, int) const { d_weight[(size_t)m * L1 + n] = v; }
+  __device__ __forceinline__ float pre(int, int) const { return 0.0f; }
+  __device__ __forceinline__ void store(int m, int n, float v, float2, float, int) const { d_weight[(size_t)m * L1 + n] = v; }
 };
 
 struct ValEpi {  // d_conv_out = acc where the position is active, else 0
@@ -70,17 +76,22 @@ struct ValEpi {  // d_conv_out = acc where the position is active, else 0
   float* __restrict__ d_conv_out;
   int P;
   __device__ __forceinline__ float2 col(int) const { return make_float2(0.f, 0.f); }
-  __device__ __forceinline__ void store(int m, int p, float v, float2, int) const {
-    const size_t o = (size_t)m * P + p;
-    d_conv_out[o] = bits[o] != 0.0f ? v : 0.0f;
+  __device__ __forceinline__ float pre(int m, int p) const { return bits[(size_t)m * P + p]; }
+  __device__ __forceinline__ void store(int m, int p, float v, float2, float bit, int) const {
+    d_conv_out[(size_t)m * P + p] = bit != 0.0f ? v : 0.0f;
   }
 };
 
 template <int BM, int BN, int BK, bool AKC, bool BKC, class Epi>
 __global__ __launch_bounds__(256) void ftm_gemm_kernel(Mat ma, Mat mb, Epi epi, int M, int N, int K, int klen, int tiles_n) {
-  constexpr int LDA = (AKC ? BK : BM) + 4, LDB = (BKC ? BK : BN) + 4;
+  constexpr int LDA = AKC ? BK : BM + 4, LDB = BKC ? BK : BN + 4;
   __shared__ __attribute__((aligned(16))) float As[(AKC ? BM : BK) * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[(BKC ? BN : BK) * LDB];
+  // KC image: unpadded rows with the 16-byte chunk index XOR-swizzled by the row, so that every 16-lane group of a
+  // fragment ds_read_b128 (16 different rows, two neighbouring chunks) lands on 16 different 16-byte slots
+  auto kc = [](int row, int k) { return row * BK + ((((k >> 2) ^ (BK == 32 ? (row >> 1) & 7 : row & 15))) << 2); };
+  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ma.p), 0, ma.bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(mb.p), 0, mb.bytes, 0x00020000);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
@@ -98,11 +109,29 @@ __global__ __launch_bounds__(256) void ftm_gemm_kernel(Mat ma, Mat mb, Epi epi, 
   float4 ra[AG], rb[BG];
   auto fetch = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < AG; ++i) ra[i] = AKC ? ma.load(m_base + a_row(i), k0 + a_k(i)) : ma.load(k0 + a_k(i), m_base + a_row(i));
+    for (int i = 0; i < AG; ++i)
+      ra[i] = AKC ? mat_load(rsa, ma, m_base + a_row(i), k0 + a_k(i)) : mat_load(rsa, ma, k0 + a_k(i), m_base + a_row(i));
 #pragma unroll
-    for (int i = 0; i < BG; ++i) rb[i] = BKC ? mb.load(n_base + b_row(i), k0 + b_k(i)) : mb.load(k0 + b_k(i), n_base + b_row(i));
+    for (int i = 0; i < BG; ++i)
+      rb[i] = BKC ? mat_load(rsb, mb, n_base + b_row(i), k0 + b_k(i)) : mat_load(rsb, mb, k0 + b_k(i), n_base + b_row(i));
   };
   const int m0 = (wave >> 1) * (BM / 2), n0 = (wave & 1) * (BN / 2);
+  // fragments of the 16-k block at kb: a lane supplies k = kb + 4q .. 4q+3 of row r of each of its tiles
+  auto frags = [&](int kb, float4 (&a)[TM], float4 (&b)[TN]) {
+    const int k = kb + 4 * q;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int x = m0 + 16 * i + r;
+      if (AKC) a[i] = *reinterpret_cast<const float4*>(&As[kc(x, k)]);
+      else a[i] = make_float4(As[k * LDA + x], As[(k + 1) * LDA + x], As[(k + 2) * LDA + x], As[(k + 3) * LDA + x]);
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      const int x = n0 + 16 * t + r;
+      if (BKC) b[t] = *reinterpret_cast<const float4*>(&Bs[kc(x, k)]);
+      else b[t] = make_float4(Bs[k * LDB + x], Bs[(k + 1) * LDB + x], Bs[(k + 2) * LDB + x], Bs[(k + 3) * LDB + x]);
+    }
+  };
   f32x4 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -112,58 +141,65 @@ __global__ __launch_bounds__(256) void ftm_gemm_kernel(Mat ma, Mat mb, Epi epi, 
   fetch(k_lo);
   for (int k0 = k_lo; k0 < k_hi; k0 += BK) {
 #pragma unroll
-    for (int i = 0; i < AG; ++i) *reinterpret_cast<float4*>(&As[AKC ? a_row(i) * LDA + a_k(i) : a_k(i) * LDA + a_row(i)]) = ra[i];
+    for (int i = 0; i < AG; ++i) *reinterpret_cast<float4*>(&As[AKC ? kc(a_row(i), a_k(i)) : a_k(i) * LDA + a_row(i)]) = ra[i];
 #pragma unroll
-    for (int i = 0; i < BG; ++i) *reinterpret_cast<float4*>(&Bs[BKC ? b_row(i) * LDB + b_k(i) : b_k(i) * LDB + b_row(i)]) = rb[i];
+    for (int i = 0; i < BG; ++i) *reinterpret_cast<float4*>(&Bs[BKC ? kc(b_row(i), b_k(i)) : b_k(i) * LDB + b_row(i)]) = rb[i];
     __syncthreads();
     if (k0 + BK < k_hi) fetch(k0 + BK);
+    float4 a[2][TM], b[2][TN];
+    frags(0, a[0], b[0]);
 #pragma unroll
     for (int kb = 0; kb < BK; kb += 16) {
-      float4 a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int x = m0 + 16 * i + r, k = kb + 4 * q;
-        if (AKC) a[i] = *reinterpret_cast<const float4*>(&As[x * LDA + k]);
-        else a[i] = make_float4(As[k * LDA + x], As[(k + 1) * LDA + x], As[(k + 2) * LDA + x], As[(k + 3) * LDA + x]);
-      }
-#pragma unroll
-      for (int t = 0; t < TN; ++t) {
-        const int x = n0 + 16 * t + r, k = kb + 4 * q;
-        if (BKC) b[t] = *reinterpret_cast<const float4*>(&Bs[x * LDB + k]);
-        else b[t] = make_float4(Bs[k * LDB + x], Bs[(k + 1) * LDB + x], Bs[(k + 2) * LDB + x], Bs[(k + 3) * LDB + x]);
-      }
+      const int cur = (kb >> 4) & 1;
+      // the next block's LDS reads are issued before this block's MFMAs and land while they run
+      if (kb + 16 < BK) frags(kb + 16, a[cur ^ 1], b[cur ^ 1]);
+      __builtin_amdgcn_sched_barrier(0);
       // consecutive MFMAs go to different accumulators
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int t = 0; t < TN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[t].x, acc[i][t], 0, 0, 0);
+        for (int t = 0; t < TN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][i].x, b[cur][t].x, acc[i][t], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int t = 0; t < TN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[t].y, acc[i][t], 0, 0, 0);
+        for (int t = 0; t < TN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][i].y, b[cur][t].y, acc[i][t], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int t = 0; t < TN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[t].z, acc[i][t], 0, 0, 0);
+        for (int t = 0; t < TN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][i].z, b[cur][t].z, acc[i][t], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int t = 0; t < TN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[t].w, acc[i][t], 0, 0, 0);
+        for (int t = 0; t < TN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][i].w, b[cur][t].w, acc[i][t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   }
-  // accumulator register e of lane 16 q + r holds C[row 4 q + e][col r]
+  // accumulator register e of lane 16 q + r holds C[row 4 q + e][col r]; every epilogue operand is loaded before
+  // the first store so that the loads overlap
+  float2 cv[TN];
+  float pre[TM][TN][4];
 #pragma unroll
   for (int t = 0; t < TN; ++t) {
     const int n = n_base + n0 + 16 * t + r;
-    if (n >= N) continue;
-    const float2 c = epi.col(n);
+    cv[t] = n < N ? epi.col(n) : make_float2(0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int m = m_base + m0 + 16 * i + 4 * q + e;
-        if (m < M) epi.store(m, n, acc[i][t][e], c, blockIdx.y);
+        pre[i][t][e] = (m < M && n < N) ? epi.pre(m, n) : 0.0f;
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int n = n_base + n0 + 16 * t + r;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m_base + m0 + 16 * i + 4 * q + e;
+        if (m < M && n < N) epi.store(m, n, acc[i][t][e], cv[t], pre[i][t][e], blockIdx.y);
       }
   }
 }
@@ -284,7 +320,7 @@ struct Shape {
   int cfg;  // 0: 32x64x128   1: 64x64x64   2: 128x64x32   3: 64x128x32
   int bm, bn, bk, tiles_m, tiles_n, ksplit, klen;
 };
-constexpr int kCfg[4][3] = {{32, 64, 128}, {64, 64, 64}, {128, 64, 32}, {64, 128, 32}};
+constexpr int kCfg[6][3] = {{32, 64, 128}, {64, 64, 64}, {128, 64, 32}, {64, 128, 32}, {128, 64, 64}, {64, 128, 64}};
 
 // prefer_m: the operand re-read per M tile is the big one (the table, in forward and value gradient), so take tall
 // tiles; otherwise (weight gradient: the map is re-read per N tile) take wide ones.  The largest preferred shape
@@ -300,7 +336,7 @@ Shape plan(int M, int N, int K, bool prefer_m, bool allow_split) {
     if (tiles(order[i]) >= 256) { cfg = order[i]; break; }
   const bool small_m = allow_split && M <= 128;
   if (small_m) cfg = 2;
-  if (force_cfg >= 0 && force_cfg < 4) cfg = force_cfg;
+  if (force_cfg >= 0 && force_cfg < 6) cfg = force_cfg;
   Shape s;
   s.cfg = cfg;
   s.bm = kCfg[cfg][0]; s.bn = kCfg[cfg][1]; s.bk = kCfg[cfg][2];
@@ -330,13 +366,18 @@ void launch(hipStream_t st, const Shape& s, Mat ma, Mat mb, Epi epi, int M, int 
     case 0: NNUE_FTM_LAUNCH(32, 64, 128); break;
     case 1: NNUE_FTM_LAUNCH(64, 64, 64); break;
     case 2: NNUE_FTM_LAUNCH(128, 64, 32); break;
-    default: NNUE_FTM_LAUNCH(64, 128, 32); break;
+    case 3: NNUE_FTM_LAUNCH(64, 128, 32); break;
+    case 4: NNUE_FTM_LAUNCH(128, 64, 64); break;
+    default: NNUE_FTM_LAUNCH(64, 128, 64); break;
   }
 #undef NNUE_FTM_LAUNCH
 }
 
+// every operand is addressed with 32-bit byte offsets (tile overhang included)
 bool shape_ok(int B, int F, int P, int L1) {
-  return B > 0 && F > 0 && P > 0 && L1 > 0 && P < (1 << 30) && (long long)B * P < (1ll << 40) && (long long)F * L1 < (1ll << 40);
+  const long long lim = (1ll << 31) - 1;
+  return B > 0 && F > 0 && P > 0 && L1 > 0 && ((long long)B + 256) * P * 4 < lim && ((long long)F + 256) * L1 * 4 < lim &&
+         ((long long)B + 256) * L1 * 4 < lim && ((long long)P + 256) * L1 * 4 < lim;
 }
 
 constexpr int kIntMax = 0x7fffffff;
@@ -394,8 +435,10 @@ extern "C" int nnue_ftm_forward(const float* bits, const float* sink, const floa
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* dst = s.ksplit > 1 ? static_cast<float*>(scratch) : out;
   const float* w_last = weight + (size_t)(F - 1) * L1;
-  launch<true, false>(st, s, Mat{bits, B, direct, P, kIntMax}, Mat{weight, direct, L1, L1, kIntMax},
-                      FwdEpi{bias, w_last, sink, dst, B, L1, s.ksplit}, B, L1, K);
+  // A = the map (its K tail needs no zeroing: the table window ends at row `direct`, so B is zero there)
+  launch<true, false>(st, s, Mat{bits, (unsigned)((size_t)B * P * 4), P, kIntMax, kIntMax},
+                      Mat{weight, (unsigned)((size_t)direct * L1 * 4), L1, kIntMax, kIntMax}, FwdEpi{bias, w_last, sink, dst, B, L1, s.ksplit}, B,
+                      L1, K);
   if (s.ksplit > 1) {
     const int64_t count4 = (int64_t)B * L1 / 4;
     hipLaunchKernelGGL(ftm_finish_kernel, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, st, dst, s.ksplit, count4, bias, w_last, sink,
@@ -415,7 +458,8 @@ extern "C" int nnue_ftm_backward_weight(const float* bits, const float* sink, co
   const int direct = (F - 1 < P) ? F - 1 : P;
   if (d_weight && direct > 0) {
     const Shape s = plan(direct, L1, B, false, false);
-    launch<false, false>(st, s, Mat{bits, B, direct, P, kIntMax}, Mat{d_out, B, L1, L1, kIntMax}, BwwEpi{d_weight, L1}, direct, L1, B);
+    launch<false, false>(st, s, Mat{bits, (unsigned)((size_t)B * P * 4), P, kIntMax, kIntMax},
+                         Mat{d_out, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, kIntMax}, BwwEpi{d_weight, L1}, direct, L1, B);
   }
   int zero_slices = (F - 1 - direct + 255) / 256;
   zero_slices = zero_slices > 256 ? 256 : zero_slices;
@@ -432,6 +476,8 @@ extern "C" int nnue_ftm_backward_values(const float* bits, const float* d_out, c
   NNUE_REQUIRE(nnue_aligned16(d_out) && nnue_aligned16(weight), NNUE_E_ARG, "nnue_ftm_backward_values: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const Shape s = plan(B, P, L1, true, false);
-  launch<true, true>(st, s, Mat{d_out, B, L1, L1, kIntMax}, Mat{weight, P, L1, L1, F - 1}, ValEpi{bits, d_conv_out, P}, B, P, L1);
+  // K = L1 runs along the inner index of both operands: A is zeroed past it, the table rows are clamped to F-1
+  launch<true, true>(st, s, Mat{d_out, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, L1},
+                     Mat{weight, (unsigned)((size_t)F * L1 * 4), L1, F - 1, kIntMax}, ValEpi{bits, d_conv_out, P}, B, P, L1);
   return nnue_launch_status("nnue_ftm_backward_values");
 }
