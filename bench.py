@@ -193,14 +193,15 @@ def main():
                for k in names}
     def pmc_traffic(entry):
         """HBM-side bytes per launch of the kernel behind a C entry point, from the committed rocprofv3 --pmc passes
-        (profiles/*pmc_traffic.json, FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; separate passes, C2
-        workload).  Counters cannot be read inside this process, so other workloads report null."""
-        if args.workload != "c2":
-            return None
+        (profiles/*pmc_traffic.json, FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; separate passes per
+        counter group).  Counters cannot be read inside this process, so workloads without a committed pass report null."""
         files = sorted((ROOT / "profiles").glob("*pmc_traffic.json"))
         if not files:
             return None
-        kernels = json.loads(files[-1].read_text())["kernels"]
+        data = json.loads(files[-1].read_text())
+        kernels = data.get("workloads", {}).get(args.workload) or (data.get("kernels") if args.workload == "c2" else None)
+        if not kernels:
+            return None
         want = {"nnue_ftm_forward": ("ftm_gemm_kernel", "FwdEpi"), "nnue_ftm_backward_weight": ("ftm_gemm_kernel", "BwwEpi"),
                 "nnue_ftm_backward_values": ("ftm_gemm_kernel", "ValEpi"),
                 "nnue_ftb_forward": ("ftb_gather_kernel", ", 0,"), "nnue_ftb_backward_weight": ("ftb_gather_kernel", ", 1,"),

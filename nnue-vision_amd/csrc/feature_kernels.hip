@@ -321,9 +321,14 @@ int ste_chunks(int B, int fps) {
   return chunks;
 }
 
+// about two tiles per workgroup (stage 2 reads one 28-vector per channel per workgroup), at least one workgroup per
+// CU once there is that much work, never more than kSteMaxBlocks
 int64_t ste_mfma_blocks(int64_t positions) {
   const int64_t tiles = (positions + kStePos - 1) / kStePos;
-  return tiles < kSteMaxBlocks ? (tiles > 0 ? tiles : 1) : kSteMaxBlocks;
+  int64_t blocks = (tiles + 1) / 2;
+  if (blocks < 256) blocks = tiles < 256 ? tiles : 256;
+  if (blocks > kSteMaxBlocks) blocks = kSteMaxBlocks;
+  return blocks > 0 ? blocks : 1;
 }
 
 }  // namespace

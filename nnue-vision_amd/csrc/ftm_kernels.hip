@@ -240,7 +240,21 @@ __global__ __launch_bounds__(256) void ftm_tail_rows_kernel(const float* __restr
   float sb = 0.f, sw = 0.f;
   if (col < L1) {
     const int per = (B + 15) / 16, lo = part * per, hi = lo + per < B ? lo + per : B;
-    for (int b = lo; b < hi; ++b) {
+    int b = lo;
+    for (; b + 8 <= hi; b += 8) {  // eight independent loads in flight; the sums keep their order
+      float d[8], s[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        d[u] = d_out[(size_t)(b + u) * L1 + col];
+        s[u] = sink[b + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        sb += d[u];
+        sw = fmaf(s[u], d[u], sw);
+      }
+    }
+    for (; b < hi; ++b) {
       const float d = d_out[(size_t)b * L1 + col];
       sb += d;
       sw = fmaf(sink[b], d, sw);
