@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 9
+#define NNUE_HIP_ABI_VERSION 10
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -266,6 +266,38 @@ int nnue_cross_entropy(const float* logits, const int64_t* labels, int B, int C,
  * once before the first batch.  Integer atomics: the result does not depend on execution order. */
 int nnue_confusion_accumulate(const float* logits, const int64_t* labels, int B, int C,
                               uint64_t* confusion, nnue_stream_t stream);
+
+/* ---- the compiled engine's integer inference, batched --------------------------------
+ *
+ * The quantised tensors of a `.nnue` file (layout: serialize.py:33-63, :103-136, :394-491; loader
+ * engine/src/nnue_engine.cpp:544-657) in device memory, scalars by value.  The struct itself is read on the
+ * host.  l1_w holds the (L2+1) x L1 bytes of the file (the last row is not used by the multiclass path);
+ * l2_w is [L3][2*L2] (first L2 columns used). */
+typedef struct nnue_engine_model {
+  int32_t num_features, l1, l2, l3, classes, grid, oc;
+  float conv_scale, threshold, quantized_one, l1_scale, l2_scale, out_scale;
+  const int8_t* conv_w;  /* [oc*27], the file's bytes */
+  const int32_t* conv_b; /* [oc] */
+  const int16_t* ft_w;   /* [num_features][l1] */
+  const int32_t* ft_b;   /* [l1] */
+  const int8_t* l1_w;
+  const int32_t* l1_b;
+  const int8_t* l2_w;
+  const int32_t* l2_b;
+  const int8_t* out_w;   /* [classes][l3] */
+  const int32_t* out_b;
+} nnue_engine_model;
+
+/* NNUEEvaluator::evaluate_logits (engine/src/nnue_engine.cpp:704-734) for B images at once -- what
+ * evaluate_compiled_model obtains from one nnue_inference subprocess per image (evaluate.py:143-176,
+ * engine/nnue_inference.cpp:42-60).  images: B flat buffers of 3*H*W floats, indexed HWC exactly as the engine
+ * indexes them.  logits [B][classes], density [B] = active features / num_features.  Integer arithmetic
+ * throughout: bit-identical to the engine.  Returns NNUE_E_SHAPE where the engine itself would write past its
+ * grid buffer (conv map larger than grid x grid).  scratch >= nnue_engine_scratch(m, B) bytes. */
+int64_t nnue_engine_scratch(const nnue_engine_model* m, int B);
+int nnue_engine_evaluate_logits(const nnue_engine_model* m, const float* images, int B, int H, int W,
+                                float* logits, float* density, void* scratch, int64_t scratch_bytes,
+                                nnue_stream_t stream);
 
 /* clip_grad_norm_ + SGD(momentum, weight_decay) on flat buffers (train.py:363-366, :457-464):
  *   g <- g * grad_scale              (1/world after a summed all-reduce)

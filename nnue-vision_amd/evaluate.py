@@ -88,3 +88,48 @@ def evaluate_model(model: torch.nn.Module, loader, loss_fn=None, device: Optiona
         raise ValueError("evaluate_model: empty loader")
     total = torch.stack(losses).double().sum().item()  # the single synchronisation
     return total / len(losses), metrics_from_confusion(confusion.cpu().numpy())
+
+
+def evaluate_compiled_model(model: torch.nn.Module, loader, model_type: str) -> Dict[str, float]:
+    """The reference's compiled-engine evaluation (evaluate.py:88-385) without the per-image subprocess: the model is
+    serialised to a temporary `.nnue` file exactly as there, the file is loaded the way the C++ engine loads it, and
+    the engine's integer `evaluate_logits` runs for whole batches on the GPU (bit-identical logits and densities,
+    include/nnue_hip.h: nnue_engine_evaluate_logits).  Returns the reference's keys: the compute_metrics dict plus
+    `ms_per_sample` (GPU time of the engine call per sample) and `latent_density` (mean active fraction)."""
+    import tempfile
+    import time
+    from pathlib import Path
+
+    from nnue_hip.engine import EngineModel
+    from serialize import serialize_model
+    if model_type == "etinynet":
+        raise NotImplementedError("EtinyNet is outside this build's scope (SURVEY section 8): use the reference's evaluate.py")
+    if model_type != "nnue":
+        raise ValueError(f"Unknown model type: {model_type}")
+    with tempfile.TemporaryDirectory() as tmp:
+        path = Path(tmp) / "model.nnue"
+        serialize_model(model, path)
+        engine = EngineModel.load(path)
+    outputs, targets, densities = [], [], []
+    seconds, samples = 0.0, 0
+    for images, labels in loader:
+        images = images.to(engine.device, non_blocking=True).float().contiguous()
+        torch.cuda.synchronize(engine.device)
+        t0 = time.perf_counter()
+        logits, density = engine.evaluate_logits(images)
+        torch.cuda.synchronize(engine.device)
+        seconds += time.perf_counter() - t0
+        samples += images.shape[0]
+        outputs.append(logits)
+        densities.append(density)
+        targets.append(labels.reshape(-1).to(engine.device))
+    if not outputs:
+        raise RuntimeError("No outputs generated during compiled model evaluation")
+    outputs, targets = torch.cat(outputs), torch.cat(targets)
+    inferred = int(targets.max().item()) + 1 if targets.numel() else 1
+    if inferred > 2 and outputs.shape[1] == 1:
+        raise RuntimeError(f"Compiled NNUE produced shape {tuple(outputs.shape)} for {inferred}-class labels.")
+    metrics = compute_metrics(outputs, targets)
+    metrics["ms_per_sample"] = seconds / samples * 1000.0 if samples else 0.0
+    metrics["latent_density"] = float(torch.cat(densities).double().mean().item())
+    return metrics

@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -67,6 +67,8 @@ SIGNATURES = {
     "nnue_confusion_accumulate": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_p, _c_p]),
     "nnue_load_batch": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_i64, _c_int, ctypes.c_uint64, ctypes.c_uint64,
                                  _c_p, _c_p, _c_p]),
+    "nnue_engine_scratch": (_c_i64, [_c_p, _c_int]),
+    "nnue_engine_evaluate_logits": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_i64, _c_p]),
     "nnue_sgd_scratch": (_c_i64, [_c_i64]),
     "nnue_adam_step": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f,
                                 _c_p, _c_p, _c_i64, _c_p]),
