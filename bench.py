@@ -166,8 +166,12 @@ def main():
     # FeatureTransformer kernel family: dense MFMA products, bit-mask/LDS-staged gather kernels or id-list kernels
     ftp = {"mfma": "nnue_ftm", "bits": "nnue_ftb", "list": "nnue_ft"}[trainer.ft_path]
     names = ["nnue_conv3x3_forward", {"mfma": "nnue_ftm_binarize", "bits": "nnue_binarize_bits", "list": "nnue_binarize_features"}[trainer.ft_path],
-             f"{ftp}_forward", "nnue_classifier_train_step",
-             f"{ftp}_backward_weight", f"{ftp}_backward_values", "nnue_ste_conv_backward", "nnue_sgd_step"]
+             f"{ftp}_forward", "nnue_classifier_train_step"]
+    # weight + value gradient (+ tail rows) go through one C call; it is one launch at launch-sized shapes and the two
+    # separate launches at the 224x224 shapes (policy in nnue_ftm_backward)
+    merged = trainer.use_mfma and trainer.merge_backward
+    names += [f"{ftp}_backward"] if merged else [f"{ftp}_backward_weight", f"{ftp}_backward_values"]
+    names += ["nnue_ste_conv_backward", "nnue_sgd_step"]
     timers = {k: [] for k in names}
     isteps = max(5, min(50, args.steps))
     for i in range(3):
@@ -189,6 +193,8 @@ def main():
         f"{ftp}_backward_values": (n_mean + 1) * row * B,
         f"{ftp}_backward_weight": n_mean * row * B,
     }
+    if merged:
+        alg = {f"{ftp}_forward": alg[f"{ftp}_forward"], f"{ftp}_backward": alg[f"{ftp}_backward_values"] + alg[f"{ftp}_backward_weight"]}
     kernels = {k: {"avg_us": round(dur_us[k], 2), **({"alg_GBps": round(alg[k] / dur_us[k] * 1e-3, 1)} if k in alg and dur_us[k] > 0 else {})}
                for k in names}
     def pmc_traffic(entry):
@@ -202,7 +208,7 @@ def main():
         kernels = data.get("workloads", {}).get(args.workload) or (data.get("kernels") if args.workload == "c2" else None)
         if not kernels:
             return None
-        want = {"nnue_ftm_forward": ("ftm_gemm_kernel", "FwdEpi"), "nnue_ftm_backward_weight": ("ftm_gemm_kernel", "BwwEpi"),
+        want = {"nnue_ftm_forward": ("ftm_gemm_kernel", "FwdEpi"), "nnue_ftm_backward": ("ftm_backward_kernel", ""), "nnue_ftm_backward_weight": ("ftm_gemm_kernel", "BwwEpi"),
                 "nnue_ftm_backward_values": ("ftm_gemm_kernel", "ValEpi"),
                 "nnue_ftb_forward": ("ftb_gather_kernel", ", 0,"), "nnue_ftb_backward_weight": ("ftb_gather_kernel", ", 1,"),
                 "nnue_ftb_backward_values": ("ftb_values_kernel", ""), "nnue_ft_forward": ("ft_forward_wide", ""),
@@ -221,6 +227,7 @@ def main():
         direct = min(trainer.F - 1, trainer.P)
         flops = {f"{ftp}_forward": 2.0 * B * direct * cfg["l1"], f"{ftp}_backward_weight": 2.0 * B * direct * cfg["l1"],
                  f"{ftp}_backward_values": 2.0 * B * trainer.P * cfg["l1"]}
+        flops[f"{ftp}_backward"] = flops[f"{ftp}_backward_weight"] + flops[f"{ftp}_backward_values"]
         achieved = flops[dom] / (dur_us[dom] * 1e-6) / 1e12 if dur_us[dom] > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": (pmc_traffic(dom) or {}).get("bytes"),

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 10
+#define NNUE_HIP_ABI_VERSION 11
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -205,6 +205,13 @@ int nnue_ftm_backward_weight(const float* bits, const float* sink, const float* 
  *   d_conv_out[b,p] = active(b,p) ? < d_out[b,:], weight[min(p,F-1),:] > : 0     for every p < P */
 int nnue_ftm_backward_values(const float* bits, const float* d_out, const float* weight,
                              int B, int F, int P, int L1, float* d_conv_out, nnue_stream_t stream);
+
+/* nnue_ftm_backward_weight + nnue_ftm_backward_values as ONE launch (autograd of nnue.py:702-708, :628-633): the
+ * two products and the tail rows are independent, so their workgroups share the chip.  Same results, bit for bit,
+ * as the two separate calls.  All three outputs are required. */
+int nnue_ftm_backward(const float* bits, const float* sink, const float* d_out, const float* weight,
+                      int B, int F, int P, int L1, float* d_weight, float* d_bias, float* d_conv_out,
+                      nnue_stream_t stream);
 
 /* ---- pairwise product + SimpleClassifier -------------------------------------- */
 

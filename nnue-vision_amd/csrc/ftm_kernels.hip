@@ -82,11 +82,20 @@ struct ValEpi {  // d_conv_out = acc where the position is active, else 0
   }
 };
 
+// LDS floats one tile needs (both staged operands)
+template <int BM, int BN, int BK, bool AKC, bool BKC>
+constexpr int gemm_lds_floats() {
+  return (AKC ? BM * BK : BK * (BM + 4)) + (BKC ? BN * BK : BK * (BN + 4));
+}
+
+// One BM x BN output tile (linear tile index `tile`, K slab `ks`) by the 256 threads of a workgroup; `smem` is the
+// workgroup's LDS (gemm_lds_floats() floats, 16-byte aligned).
 template <int BM, int BN, int BK, bool AKC, bool BKC, class Epi>
-__global__ __launch_bounds__(256) void ftm_gemm_kernel(Mat ma, Mat mb, Epi epi, int M, int N, int K, int klen, int tiles_n) {
+__device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& ma, const Mat& mb, const Epi& epi, int M, int N, int K,
+                                          int klen, int tiles_n, int tile, int ks) {
   constexpr int LDA = AKC ? BK : BM + 4, LDB = BKC ? BK : BN + 4;
-  __shared__ __attribute__((aligned(16))) float As[(AKC ? BM : BK) * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[(BKC ? BN : BK) * LDB];
+  float* __restrict__ As = smem;
+  float* __restrict__ Bs = smem + (AKC ? BM : BK) * LDA;
   // KC image: unpadded rows with the 16-byte chunk index XOR-swizzled by the row, so that every 16-lane group of a
   // fragment ds_read_b128 (16 different rows, two neighbouring chunks) lands on 16 different 16-byte slots
   auto kc = [](int row, int k) { return row * BK + ((((k >> 2) ^ (BK == 32 ? (row >> 1) & 7 : row & 15))) << 2); };
@@ -95,9 +104,9 @@ __global__ __launch_bounds__(256) void ftm_gemm_kernel(Mat ma, Mat mb, Epi epi, 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
-  const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
+  const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
   const int m_base = tile_m * BM, n_base = tile_n * BN;
-  const int k_lo = blockIdx.y * klen;
+  const int k_lo = ks * klen;
   const int k_hi = (k_lo + klen < K) ? k_lo + klen : K;
   constexpr int AG = BM * BK / 1024, BG = BN * BK / 1024;  // float4 groups per thread
   constexpr int TM = BM / 32, TN = BN / 32;
@@ -199,9 +208,15 @@ __global__ __launch_bounds__(256) void ftm_gemm_kernel(Mat ma, Mat mb, Epi epi, 
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int m = m_base + m0 + 16 * i + 4 * q + e;
-        if (m < M && n < N) epi.store(m, n, acc[i][t][e], cv[t], pre[i][t][e], blockIdx.y);
+        if (m < M && n < N) epi.store(m, n, acc[i][t][e], cv[t], pre[i][t][e], ks);
       }
   }
+}
+
+template <int BM, int BN, int BK, bool AKC, bool BKC, class Epi>
+__global__ __launch_bounds__(256) void ftm_gemm_kernel(Mat ma, Mat mb, Epi epi, int M, int N, int K, int klen, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) float smem[gemm_lds_floats<BM, BN, BK, AKC, BKC>()];
+  gemm_tile<BM, BN, BK, AKC, BKC, Epi>(smem, ma, mb, epi, M, N, K, klen, tiles_n, blockIdx.x, blockIdx.y);
 }
 
 // out = bias + sink[b] * weight[F-1] + sum of the split-K slabs (fixed order)
@@ -226,15 +241,27 @@ __global__ __launch_bounds__(256) void ftm_finish_kernel(const float* __restrict
 // The rows of the weight gradient that are not positions of the map, and the bias gradient:
 //   d_bias = sum_b d_out[b], d_weight[F-1] = sum_b sink[b] d_out[b], d_weight[direct .. F-2] = 0.
 // grid (ceil(L1 / 16), 1 + zero-fill slices); block y = 0 reduces 16 columns over the batch in sixteen fixed slices.
-__global__ __launch_bounds__(256) void ftm_tail_rows_kernel(const float* __restrict__ d_out, const float* __restrict__ sink,
-                                                            int B, int L1, int direct, int F, float* __restrict__ d_weight,
-                                                            float* __restrict__ d_bias) {
+struct TailRows {
+  const float* d_out;
+  const float* sink;
+  int B, L1, direct, F;
+  float* d_weight;
+  float* d_bias;
+  int col_blocks, zero_slices;  // block grid: col_blocks x (1 + zero_slices)
+};
+
+__device__ __forceinline__ void tail_rows_block(const TailRows& t, int bx, int by) {
   __shared__ float red[2][16][16];
+  const float* __restrict__ d_out = t.d_out;
+  const float* __restrict__ sink = t.sink;
+  float* __restrict__ d_weight = t.d_weight;
+  float* __restrict__ d_bias = t.d_bias;
+  const int B = t.B, L1 = t.L1, direct = t.direct, F = t.F;
   const int c = threadIdx.x & 15, part = threadIdx.x >> 4;
-  const int col = blockIdx.x * 16 + c;
-  if (blockIdx.y > 0) {  // zero rows the map cannot reach
+  const int col = bx * 16 + c;
+  if (by > 0) {  // zero rows the map cannot reach
     if (d_weight && col < L1)
-      for (int f = direct + (int)(blockIdx.y - 1) * 16 + part; f < F - 1; f += 16 * ((int)gridDim.y - 1)) d_weight[(size_t)f * L1 + col] = 0.0f;
+      for (int f = direct + (by - 1) * 16 + part; f < F - 1; f += 16 * t.zero_slices) d_weight[(size_t)f * L1 + col] = 0.0f;
     return;
   }
   float sb = 0.f, sw = 0.f;
@@ -272,6 +299,28 @@ __global__ __launch_bounds__(256) void ftm_tail_rows_kernel(const float* __restr
     } else if (d_weight) {
       d_weight[(size_t)(F - 1) * L1 + col] = s;
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void ftm_tail_rows_kernel(TailRows t) { tail_rows_block(t, blockIdx.x, blockIdx.y); }
+
+// Weight gradient, value gradient and the tail rows in ONE launch: they are independent (all three read d_out), so
+// their workgroups share the chip instead of queueing behind two kernel boundaries.  Blocks [0, n_w) are weight-gradient
+// tiles, [n_w, n_w + n_v) value-gradient tiles, the rest tail-row blocks.
+template <int WM, int WN, int WK, int VM, int VN, int VK>
+__global__ __launch_bounds__(256) void ftm_backward_kernel(Mat wa, Mat wb, BwwEpi we, int wM, int wN, int wK, int w_tiles_n, int n_w,
+                                                           Mat va, Mat vb, ValEpi ve, int vM, int vN, int vK, int v_tiles_n, int n_v,
+                                                           TailRows t) {
+  constexpr int kW = gemm_lds_floats<WM, WN, WK, false, false>(), kV = gemm_lds_floats<VM, VN, VK, true, true>();
+  __shared__ __attribute__((aligned(16))) float smem[kW > kV ? kW : kV];
+  const int blk = blockIdx.x;
+  if (blk < n_w) {
+    gemm_tile<WM, WN, WK, false, false, BwwEpi>(smem, wa, wb, we, wM, wN, wK, wK + WK, w_tiles_n, blk, 0);
+  } else if (blk < n_w + n_v) {
+    gemm_tile<VM, VN, VK, true, true, ValEpi>(smem, va, vb, ve, vM, vN, vK, vK + VK, v_tiles_n, blk - n_w, 0);
+  } else {
+    const int i = blk - n_w - n_v;
+    tail_rows_block(t, i % t.col_blocks, i / t.col_blocks);
   }
 }
 
@@ -388,6 +437,12 @@ void launch(hipStream_t st, const Shape& s, Mat ma, Mat mb, Epi epi, int M, int 
 }
 
 // every operand is addressed with 32-bit byte offsets (tile overhang included)
+TailRows tail_rows(const float* d_out, const float* sink, int B, int L1, int direct, int F, float* d_weight, float* d_bias) {
+  int zero_slices = d_weight ? (F - 1 - direct + 255) / 256 : 0;
+  zero_slices = zero_slices > 256 ? 256 : zero_slices;
+  return TailRows{d_out, sink, B, L1, direct, F, d_weight, d_bias, (L1 + 15) / 16, zero_slices};
+}
+
 bool shape_ok(int B, int F, int P, int L1) {
   const long long lim = (1ll << 31) - 1;
   return B > 0 && F > 0 && P > 0 && L1 > 0 && ((long long)B + 256) * P * 4 < lim && ((long long)F + 256) * L1 * 4 < lim &&
@@ -475,10 +530,8 @@ extern "C" int nnue_ftm_backward_weight(const float* bits, const float* sink, co
     launch<false, false>(st, s, Mat{bits, (unsigned)((size_t)B * P * 4), P, kIntMax, kIntMax},
                          Mat{d_out, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, kIntMax}, BwwEpi{d_weight, L1}, direct, L1, B);
   }
-  int zero_slices = (F - 1 - direct + 255) / 256;
-  zero_slices = zero_slices > 256 ? 256 : zero_slices;
-  hipLaunchKernelGGL(ftm_tail_rows_kernel, dim3((L1 + 15) / 16, 1 + (d_weight ? zero_slices : 0)), dim3(256), 0, st, d_out, sink, B, L1, direct, F,
-                     d_weight, d_bias);
+  const TailRows t = tail_rows(d_out, sink, B, L1, direct, F, d_weight, d_bias);
+  hipLaunchKernelGGL(ftm_tail_rows_kernel, dim3(t.col_blocks, 1 + t.zero_slices), dim3(256), 0, st, t);
   return nnue_launch_status("nnue_ftm_backward_weight");
 }
 
@@ -494,4 +547,40 @@ extern "C" int nnue_ftm_backward_values(const float* bits, const float* d_out, c
   launch<true, true>(st, s, Mat{d_out, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, L1},
                      Mat{weight, (unsigned)((size_t)F * L1 * 4), L1, F - 1, kIntMax}, ValEpi{bits, d_conv_out, P}, B, P, L1);
   return nnue_launch_status("nnue_ftm_backward_values");
+}
+
+// Both gradients of the binary-map FeatureTransformer in one launch (see ftm_backward_kernel); falls back to the two
+// separate launches for tile-shape pairs that are not instantiated.
+extern "C" int nnue_ftm_backward(const float* bits, const float* sink, const float* d_out, const float* weight, int B, int F, int P,
+                                 int L1, float* d_weight, float* d_bias, float* d_conv_out, nnue_stream_t stream) {
+  NNUE_REQUIRE(bits && sink && d_out && weight && d_weight && d_bias && d_conv_out, NNUE_E_ARG, "nnue_ftm_backward: null pointer");
+  NNUE_REQUIRE(shape_ok(B, F, P, L1), NNUE_E_ARG, "nnue_ftm_backward: B=%d F=%d P=%d L1=%d out of range", B, F, P, L1);
+  NNUE_REQUIRE(nnue_ftm_supported(F, P, L1), NNUE_E_SHAPE, "nnue_ftm_backward: P=%d and L1=%d must be multiples of 4", P, L1);
+  NNUE_REQUIRE(nnue_aligned16(bits) && nnue_aligned16(d_out) && nnue_aligned16(weight), NNUE_E_ARG,
+               "nnue_ftm_backward: pointers must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int direct = (F - 1 < P) ? F - 1 : P;
+  static const int split_launch = env_int("NNUE_FTM_SPLIT_BACKWARD", 0);
+  const Shape sw = plan(direct > 0 ? direct : 1, L1, B, false, false), sv = plan(B, P, L1, true, false);
+  // measured: one launch wins where the products are launch-sized (C2 -10 %, C3 -8 % of the two launches) and loses
+  // 7 % at the 224x224 shapes, where each product fills the chip by itself and the two tile shapes fight over L2
+  const bool pair_ok = sw.cfg == 0 && (sv.cfg == 0 || sv.cfg == 1);
+  if (direct <= 0 || !pair_ok || split_launch) {
+    const int rc = nnue_ftm_backward_weight(bits, sink, d_out, B, F, P, L1, d_weight, d_bias, stream);
+    return rc != NNUE_OK ? rc : nnue_ftm_backward_values(bits, d_out, weight, B, F, P, L1, d_conv_out, stream);
+  }
+  const Mat wa{bits, (unsigned)((size_t)B * P * 4), P, kIntMax, kIntMax}, wb{d_out, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, kIntMax};
+  const Mat va{d_out, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, L1}, vb{weight, (unsigned)((size_t)F * L1 * 4), L1, F - 1, kIntMax};
+  const BwwEpi we{d_weight, L1};
+  const ValEpi ve{bits, d_conv_out, P};
+  const TailRows t = tail_rows(d_out, sink, B, L1, direct, F, d_weight, d_bias);
+  const int n_w = sw.tiles_m * sw.tiles_n, n_v = sv.tiles_m * sv.tiles_n, n_t = t.col_blocks * (1 + t.zero_slices);
+  const dim3 grid((unsigned)(n_w + n_v + n_t));
+#define NNUE_FTM_BWD(WM, WN, WK, VM, VN, VK)                                                                                          \
+  hipLaunchKernelGGL((ftm_backward_kernel<WM, WN, WK, VM, VN, VK>), grid, dim3(256), 0, st, wa, wb, we, direct, L1, B, sw.tiles_n, n_w, va, \
+                     vb, ve, B, P, L1, sv.tiles_n, n_v, t)
+  if (sv.cfg == 0) NNUE_FTM_BWD(32, 64, 128, 32, 64, 128);
+  else NNUE_FTM_BWD(32, 64, 128, 64, 64, 64);
+#undef NNUE_FTM_BWD
+  return nnue_launch_status("nnue_ftm_backward");
 }

@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -51,6 +51,7 @@ SIGNATURES = {
     "nnue_ftm_forward": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_i64, _c_p]),
     "nnue_ftm_backward_weight": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
     "nnue_ftm_backward_values": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p]),
+    "nnue_ftm_backward": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p]),
     "nnue_classifier_scratch": (_c_i64, [_c_int, _c_int, _c_int, _c_int]),
     "nnue_classifier_forward": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_f,
                                          _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p,
@@ -553,6 +554,27 @@ def ftm_backward_values(d_out: torch.Tensor, weight: torch.Tensor, fm: FeatureMa
     _call("nnue_ftm_backward_values", fm.bits.data_ptr(), d_out.data_ptr(), weight.data_ptr(), b, fm.num_rows, fm.positions,
           l1, dst.data_ptr(), _stream(d_out))
     return dst
+
+
+def ftm_backward(d_out: torch.Tensor, weight: torch.Tensor, fm: FeatureMatrix, d_weight: Optional[torch.Tensor] = None,
+                 d_bias: Optional[torch.Tensor] = None, dst: Optional[torch.Tensor] = None):
+    """(d_weight, d_bias, d_conv_out) in one launch; bitwise the results of ftm_backward_weight + ftm_backward_values."""
+    d_out = _need(d_out, torch.float32, "d_out")
+    weight = _need(weight, torch.float32, "input.weight")
+    b, l1 = d_out.shape
+    if tuple(weight.shape) != (fm.num_rows, l1) or b != fm.batch:
+        raise ValueError("ftm_backward: shape mismatch")
+    if d_weight is None:
+        d_weight = torch.empty((fm.num_rows, l1), dtype=torch.float32, device=d_out.device)
+    if d_bias is None:
+        d_bias = torch.empty((l1,), dtype=torch.float32, device=d_out.device)
+    if dst is None:
+        dst = torch.empty((b, fm.positions), dtype=torch.float32, device=d_out.device)
+    elif dst.numel() != b * fm.positions:
+        raise ValueError("ftm_backward: dst has the wrong size")
+    _call("nnue_ftm_backward", fm.bits.data_ptr(), fm.sink.data_ptr(), d_out.data_ptr(), weight.data_ptr(), b, fm.num_rows,
+          fm.positions, l1, d_weight.data_ptr(), d_bias.data_ptr(), dst.data_ptr(), _stream(d_out))
+    return d_weight, d_bias, dst
 
 
 # ---------------------------------------------------------------------------- classifier

@@ -195,6 +195,8 @@ class NnueTrainer:
         # ROCm 7.0 (C2): 0.230 ms/step forked vs 0.175 ms/step as one chain -- the graph's fork/join edges cost
         # more than the overlap returns, so the default is the linear chain.
         self.branch = os.environ.get("NNUE_GRAPH_BRANCHES", "0") == "1"
+        # forked capture runs "ft_wgrad" beside "tail", which then must not depend on it
+        self.merge_backward = not self.branch and os.environ.get("NNUE_FTM_SPLIT_BACKWARD", "0") != "1"
 
     # ------------------------------------------------------------------ kernel sequences
     def _cls_params(self):
@@ -240,7 +242,11 @@ class NnueTrainer:
                 lib.ft_forward(p["input.weight"], p["input.bias"], self.act, out=self.ft)
             self._cls_step(1)
         elif name == "ft_wgrad":
-            if self.use_mfma:
+            if self.use_mfma and self.merge_backward:
+                # weight gradient, value gradient and tail rows share one launch (independent work, all read d_ft)
+                lib.ftm_backward(self.d_ft, p["input.weight"], self.fm, d_weight=g["input.weight"], d_bias=g["input.bias"],
+                                 dst=self.d_conv_out)
+            elif self.use_mfma:
                 lib.ftm_backward_weight(self.d_ft, self.fm, d_weight=g["input.weight"], d_bias=g["input.bias"])
             elif self.use_bits:
                 lib.ftb_backward_weight(self.d_ft, self.bits, d_weight=g["input.weight"], d_bias=g["input.bias"])
@@ -249,7 +255,9 @@ class NnueTrainer:
         elif name == "cls_wgrad":
             self._cls_step(2)
         elif name == "tail":
-            if self.use_mfma:
+            if self.use_mfma and self.merge_backward:
+                pass  # d_conv_out came out of the merged launch in "ft_wgrad"
+            elif self.use_mfma:
                 lib.ftm_backward_values(self.d_ft, p["input.weight"], self.fm, dst=self.d_conv_out)
             elif self.use_bits:
                 lib.ftb_backward_values(self.d_ft, p["input.weight"], self.bits, dst=self.d_conv_out)

@@ -131,3 +131,21 @@ def test_ftm_argument_errors(hip):
         hip.ftm_backward_values(torch.zeros(3, 8, device=DEV), torch.zeros(36, 8, device=DEV), fm)
     with pytest.raises(hip.NnueHipError):
         hip.ftm_binarize(conv_out.cpu(), thr.cpu(), 27, 8)
+
+
+@pytest.mark.parametrize("shape", [(512, 8, 11, 11, 800, 1024), (1024, 8, 11, 11, 800, 1024), (128, 64, 32, 32, 65536, 1024),
+                                   (37, 4, 8, 8, 256, 64), (5, 4, 3, 3, 100, 36)])
+def test_merged_backward_is_bitwise_the_two_launches(hip, shape):
+    """nnue_ftm_backward (one launch) against nnue_ftm_backward_weight + nnue_ftm_backward_values: every tile-shape pair
+    the policy picks for the BASELINE configurations, and shapes that fall back to the two launches."""
+    b, fps, gh, gw, f, l1 = shape
+    gen = torch.Generator().manual_seed(f + b)
+    conv_out = torch.randn(b, fps, gh, gw, generator=gen).to(DEV)
+    thr = torch.full((fps,), 0.17).to(DEV)
+    weight = (torch.randn(f, l1, generator=gen) * 0.1).to(DEV)
+    d_out = (torch.randn(b, l1, generator=gen) / b).to(DEV)
+    fm = hip.ftm_binarize(conv_out, thr, f, l1)
+    d_w, d_b = hip.ftm_backward_weight(d_out, fm)
+    d_v = hip.ftm_backward_values(d_out, weight, fm)
+    m_w, m_b, m_v = hip.ftm_backward(d_out, weight, fm)
+    assert torch.equal(m_w, d_w) and torch.equal(m_b, d_b) and torch.equal(m_v, d_v)
