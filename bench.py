@@ -165,8 +165,9 @@ def main():
     # ---- instrumented pass: per-entry-point durations from HIP events on the launch stream
     # FeatureTransformer kernel family: dense MFMA products, bit-mask/LDS-staged gather kernels or id-list kernels
     ftp = {"mfma": "nnue_ftm", "bits": "nnue_ftb", "list": "nnue_ft"}[trainer.ft_path]
-    names = ["nnue_conv3x3_forward", {"mfma": "nnue_ftm_binarize", "bits": "nnue_binarize_bits", "list": "nnue_binarize_features"}[trainer.ft_path],
-             f"{ftp}_forward", "nnue_classifier_train_step"]
+    names = (["nnue_ftm_conv_binarize"] if trainer.use_mfma else
+             ["nnue_conv3x3_forward", {"bits": "nnue_binarize_bits", "list": "nnue_binarize_features"}[trainer.ft_path]])
+    names += [f"{ftp}_forward", "nnue_classifier_train_step"]
     # weight + value gradient (+ tail rows) go through one C call; it is one launch at launch-sized shapes and the two
     # separate launches at the 224x224 shapes (policy in nnue_ftm_backward)
     merged = trainer.use_mfma and trainer.merge_backward

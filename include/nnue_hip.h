@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 11
+#define NNUE_HIP_ABI_VERSION 12
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -189,6 +189,12 @@ int64_t nnue_ftm_scratch(int B, int F, int P, int L1); /* bytes for nnue_ftm_for
 int nnue_ftm_binarize(const float* conv_out, const float* thr, int B, int fps, int Gh, int Gw, int F,
                       float* bits, int32_t* n, float* sink, nnue_stream_t stream);
 
+/* nnue_conv3x3_forward + nnue_ftm_binarize in one launch (self.conv + StraightThroughBinary.forward, nnue.py:640,
+ * :646-647, :19-25): conv_out, bits, n and sink are bitwise what the two calls give. */
+int nnue_ftm_conv_binarize(const float* images, const float* weight, const float* thr, int B, int H, int W,
+                           int fps, int stride, int F, float* conv_out, float* bits, int32_t* n, float* sink,
+                           nnue_stream_t stream);
+
 /* FeatureTransformer.forward for the binary map (nnue.py:686-710):
  *   out[b,:] = bias + sum_{p active, p < min(F-1,P)} weight[p,:] + sink[b] * weight[F-1,:] */
 int nnue_ftm_forward(const float* bits, const float* sink, const float* weight, const float* bias,
@@ -244,7 +250,9 @@ int nnue_classifier_backward(const float* x, int pairwise,
  * layers, the loss and their backward run per sample in a single kernel.  d_x may be NULL.
  * phases: 1 = activations, per-sample losses and d_x (the critical path of a training step), 2 = the mean loss
  * and the six weight/bias gradients (needs phase 1 on the same scratch; nothing downstream waits for it, so a
- * caller may run it on a second stream), 3 = both.
+ * caller may run it on a second stream), 3 = both.  Adding 4 (phases 5 then 6, or 7) moves the first-layer weight
+ * product into phase 1's d_x launch -- both only need d_z1, so the two small products share the chip; the phase-2
+ * call (same arguments) then only sums its slabs.  Results are identical either way.
  * scratch >= nnue_classifier_train_scratch(B, L1, L2, L3, C) bytes. */
 int64_t nnue_classifier_train_scratch(int B, int L1, int L2, int L3, int C);
 int nnue_classifier_train_step(const float* x, int pairwise,

@@ -190,15 +190,15 @@ __global__ __launch_bounds__(256) void l1_forward_mfma(const float* __restrict__
 // lane loads one dword per tile row/column block.
 constexpr int kBwTileM = 2, kBwTileN = 4;
 
-__global__ __launch_bounds__(256) void l1_backward_w_mfma(const float* __restrict__ x, int pairwise,
-                                                          const float* __restrict__ d_z1, int B, int L1, int L2,
-                                                          int ksplit, int klen, float* __restrict__ part) {
+__device__ __forceinline__ void l1_backward_w_body(const float* __restrict__ x, int pairwise, const float* __restrict__ d_z1,
+                                                   int B, int L1, int L2, int ksplit, int klen, float* __restrict__ part,
+                                                   long long block) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, q = lane >> 4;
   const int m_groups = L2 / (16 * kBwTileM);  // L2 % 32 == 0
   const int n_groups = L1 / (16 * kBwTileN);  // L1 % 64 == 0
-  long long wid = (long long)blockIdx.x * 4 + wave;
+  long long wid = block * 4 + wave;
   if (wid >= (long long)m_groups * n_groups * ksplit) return;
   const int ks = (int)(wid % ksplit);
   wid /= ksplit;
@@ -277,17 +277,16 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
 // d_x = (d_z1 W1) through the pairwise block ("NN": A contiguous along K = L2, B along N).  A wave
 // owns 16 samples x two 16-column tiles: columns j and j + L1/2 when pairwise (the pairwise backward
 // needs both), adjacent tiles otherwise.
-__global__ __launch_bounds__(256) void l1_backward_x_mfma(const float* __restrict__ x, int pairwise,
-                                                          const float* __restrict__ w1,
-                                                          const float* __restrict__ d_z1, int B, int L1, int L2,
-                                                          float* __restrict__ d_x) {
+__device__ __forceinline__ void l1_backward_x_body(const float* __restrict__ x, int pairwise, const float* __restrict__ w1,
+                                                   const float* __restrict__ d_z1, int B, int L1, int L2,
+                                                   float* __restrict__ d_x, long long block) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, q = lane >> 4;
   const int half = L1 / 2;
   const int n_pairs = L1 / 32;
   const int m_tiles = (B + 15) / 16;
-  const long long wid = (long long)blockIdx.x * 4 + wave;
+  const long long wid = block * 4 + wave;
   if (wid >= (long long)m_tiles * n_pairs) return;
   const int np = (int)(wid % n_pairs);
   const int mt = (int)(wid / n_pairs);
@@ -342,6 +341,29 @@ __global__ __launch_bounds__(256) void l1_backward_x_mfma(const float* __restric
       o[c1 + r] = acc1[e];
     }
   }
+}
+
+__global__ __launch_bounds__(256) void l1_backward_w_mfma(const float* __restrict__ x, int pairwise,
+                                                          const float* __restrict__ d_z1, int B, int L1, int L2,
+                                                          int ksplit, int klen, float* __restrict__ part) {
+  l1_backward_w_body(x, pairwise, d_z1, B, L1, L2, ksplit, klen, part, blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void l1_backward_x_mfma(const float* __restrict__ x, int pairwise,
+                                                          const float* __restrict__ w1,
+                                                          const float* __restrict__ d_z1, int B, int L1, int L2,
+                                                          float* __restrict__ d_x) {
+  l1_backward_x_body(x, pairwise, w1, d_z1, B, L1, L2, d_x, blockIdx.x);
+}
+
+// d_x and the d_w1 slabs in one launch: both only need d_z1, so the two small products share the chip instead of
+// running back to back.  Blocks [0, x_blocks) form d_x, the rest the weight-gradient slabs.
+__global__ __launch_bounds__(256) void l1_backward_xw_mfma(const float* __restrict__ x, int pairwise,
+                                                           const float* __restrict__ w1, const float* __restrict__ d_z1,
+                                                           int B, int L1, int L2, float* __restrict__ d_x, int x_blocks,
+                                                           int ksplit, int klen, float* __restrict__ part) {
+  if ((int)blockIdx.x < x_blocks) l1_backward_x_body(x, pairwise, w1, d_z1, B, L1, L2, d_x, blockIdx.x);
+  else l1_backward_w_body(x, pairwise, d_z1, B, L1, L2, ksplit, klen, part, (long long)blockIdx.x - x_blocks);
 }
 
 // ------------------------------------------------------------------ narrow layers (per sample, LDS)
@@ -778,7 +800,8 @@ extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const fl
                                           void* scratch, int64_t scratch_bytes, int phases, nnue_stream_t stream) {
   NNUE_REQUIRE(x && w1 && b1 && w2 && b2 && w3 && b3 && labels && h1 && h2 && logits && sample_loss && loss && scratch,
                NNUE_E_ARG, "nnue_classifier_train_step: null pointer");
-  NNUE_REQUIRE(phases >= 1 && phases <= 3, NNUE_E_ARG, "nnue_classifier_train_step: phases must be 1 (activations + d_x), 2 (weight gradients + loss) or 3 (both)");
+  NNUE_REQUIRE(phases >= 1 && phases <= 7 && (phases & 3), NNUE_E_ARG,
+               "nnue_classifier_train_step: phases = 1 (activations + d_x) | 2 (weight gradients + loss) [| 4: first-layer weight product beside d_x]");
   NNUE_REQUIRE(d_w1 && d_b1 && d_w2 && d_b2 && d_w3 && d_b3, NNUE_E_ARG, "nnue_classifier_train_step: null gradient pointer");
   NNUE_REQUIRE(B > 0 && L1 > 0 && L2 > 0 && L3 > 0 && C > 0, NNUE_E_ARG,
                "nnue_classifier_train_step: B=%d L1=%d L2=%d L3=%d C=%d must be positive", B, L1, L2, L3, C);
@@ -795,6 +818,10 @@ extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const fl
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* base = static_cast<float*>(scratch);
   float *part = base + t.part, *d_z1 = base + t.d_z1, *d_z2 = base + t.d_z2, *d_logits = base + t.d_logits, *slabs = base + t.slabs;
+  const bool slab_pass = p.bww_mfma && p.bww_ksplit > 1;
+  // bit 4: the d_w1 product runs in phase 1's d_x launch (both MFMA forms, d_x requested); a later phase-2 call with the
+  // same bit then only sums its slabs
+  const bool early_bww = (phases & 4) && p.bwx_mfma && p.bww_mfma && d_x != nullptr;
   if (phases & 1) {
     if (p.fwd_mfma) {
       const long long waves = (long long)((B + 15) / 16) * ((L2 + 63) / 64) * p.fwd_ksplit;
@@ -806,7 +833,12 @@ extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const fl
     hipLaunchKernelGGL(tail_train_kernel, dim3(B), dim3(128), (size_t)tail_lds, s, part, p.fwd_ksplit, b1, w2, b2, w3, b3, clip, labels,
                        grad_scale / (float)B, B, L2, L3, C, h1, h2, logits, sample_loss, d_logits, d_z1, d_z2);
     if (d_x) {
-      if (p.bwx_mfma) {
+      if (p.bwx_mfma && early_bww) {
+        const long long xw = (long long)((B + 15) / 16) * (L1 / 32), ww = (long long)(L2 / 32) * (L1 / 64) * p.bww_ksplit;
+        const int x_blocks = (int)((xw + 3) / 4);
+        hipLaunchKernelGGL(l1_backward_xw_mfma, dim3((unsigned)(x_blocks + (ww + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1, L2,
+                           d_x, x_blocks, p.bww_ksplit, p.bww_klen, slab_pass ? slabs : d_w1);
+      } else if (p.bwx_mfma) {
         const long long waves = (long long)((B + 15) / 16) * (L1 / 32);
         hipLaunchKernelGGL(l1_backward_x_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1, L2, d_x);
       } else {
@@ -816,8 +848,9 @@ extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const fl
     }
   }
   if (phases & 2) {  // needs phase 1's h1, h2, d_logits, d_z1, d_z2 (scratch) -- nothing downstream depends on it
-    const bool slab_pass = p.bww_mfma && p.bww_ksplit > 1;
-    if (p.bww_mfma) {
+    if (early_bww) {
+      // the first-layer product already ran beside d_x (phases bit 4)
+    } else if (p.bww_mfma) {
       const long long waves = (long long)(L2 / 32) * (L1 / 64) * p.bww_ksplit;
       hipLaunchKernelGGL(l1_backward_w_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, d_z1, B, L1, L2, p.bww_ksplit,
                          p.bww_klen, slab_pass ? slabs : d_w1);

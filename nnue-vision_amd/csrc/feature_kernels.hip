@@ -54,6 +54,88 @@ __global__ __launch_bounds__(256) void conv3x3_forward_kernel(const float* __res
   }
 }
 
+// Conv forward + StraightThroughBinary.forward as the float {0,1} map + per-sample counts in one launch (the
+// front of the MFMA FeatureTransformer path): same fmaf chain as conv3x3_forward_kernel, so conv_out is bitwise the
+// same; bits[b][c*G+hw] = conv_out > thr[c]; n[b] / sink[b] as nnue_ftm_binarize.  grid (B, slices): a workgroup
+// walks positions hw = y*T + tid, y*T + tid + slices*T, ... of one sample; with one slice per sample the counts are
+// plain stores, otherwise integer-valued atomics into host-zeroed counters (exact in any order).
+__global__ __launch_bounds__(256) void conv_binarize_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                            const float* __restrict__ thr, float* __restrict__ out,
+                                                            float* __restrict__ bits, int* __restrict__ n,
+                                                            float* __restrict__ sink, int H, int W, int fps, int stride,
+                                                            int Gh, int Gw, int F, int slices) {
+  extern __shared__ float w_lds[];  // [fps][27] | thr [fps]
+  __shared__ int cnt_s[4], sink_s[4];
+  float* thr_lds = w_lds + fps * 27;
+  for (int i = threadIdx.x; i < fps * 27; i += blockDim.x) w_lds[i] = w[i];
+  for (int i = threadIdx.x; i < fps; i += blockDim.x) thr_lds[i] = thr[i];
+  __syncthreads();
+  const int G = Gh * Gw;
+  const int b = blockIdx.x;
+  int cnt = 0, snk = 0;
+  for (int hw = blockIdx.y * blockDim.x + threadIdx.x; hw < G; hw += blockDim.x * slices) {
+    const int h = hw / Gw, x = hw - h * Gw;
+    float patch[27];
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int iy = h * stride + kh - 1, ix = x * stride + kw - 1;
+          const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+          patch[ci * 9 + kh * 3 + kw] = in ? img[(((size_t)b * 3 + ci) * H + iy) * W + ix] : 0.0f;
+        }
+    for (int c0 = 0; c0 < fps; c0 += kConvChunk) {
+      float acc[kConvChunk];
+#pragma unroll
+      for (int u = 0; u < kConvChunk; ++u) acc[u] = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 27; ++q)
+#pragma unroll
+        for (int u = 0; u < kConvChunk; ++u) {
+          const int c = (c0 + u < fps) ? c0 + u : fps - 1;  // clamp keeps the LDS read in range
+          acc[u] = fmaf(patch[q], w_lds[c * 27 + q], acc[u]);
+        }
+#pragma unroll
+      for (int u = 0; u < kConvChunk; ++u)
+        if (c0 + u < fps) {
+          const int p = (c0 + u) * G + hw;
+          const size_t o = (size_t)b * fps * G + p;
+          const bool on = acc[u] > thr_lds[c0 + u];
+          out[o] = acc[u];
+          bits[o] = on ? 1.0f : 0.0f;
+          cnt += on;
+          snk += on && p >= F - 1;
+        }
+    }
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    cnt += __shfl_xor(cnt, s);
+    snk += __shfl_xor(snk, s);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    cnt_s[threadIdx.x >> 6] = cnt;
+    sink_s[threadIdx.x >> 6] = snk;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int total = 0, st = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) {
+      total += cnt_s[i];
+      st += sink_s[i];
+    }
+    if (slices == 1) {
+      n[b] = total;
+      sink[b] = (float)st;
+    } else {
+      atomicAdd(&n[b], total);
+      if (st) atomicAdd(&sink[b], (float)st);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ binarise + compact
 // One workgroup per sample walks the flat ids p = c*G + hw in ascending order, 256 at a time:
 // bit = conv_out > thr[c]; wave ballots + a 4-entry LDS scan give each active id its slot, so the
@@ -346,6 +428,35 @@ extern "C" int nnue_conv3x3_forward(const float* images, const float* weight, fl
   hipLaunchKernelGGL(conv3x3_forward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), fps * 27 * sizeof(float),
                      static_cast<hipStream_t>(stream), images, weight, conv_out, B, H, W, fps, stride, Gh, Gw);
   return nnue_launch_status("nnue_conv3x3_forward");
+}
+
+extern "C" int nnue_ftm_conv_binarize(const float* images, const float* weight, const float* thr, int B, int H, int W, int fps,
+                                      int stride, int F, float* conv_out, float* bits, int32_t* n, float* sink,
+                                      nnue_stream_t stream) {
+  NNUE_REQUIRE(images && weight && thr && conv_out && bits && n && sink, NNUE_E_ARG, "nnue_ftm_conv_binarize: null pointer");
+  NNUE_REQUIRE(B > 0 && H > 0 && W > 0 && fps > 0 && stride > 0 && F > 0, NNUE_E_ARG,
+               "nnue_ftm_conv_binarize: B=%d H=%d W=%d fps=%d stride=%d F=%d must be positive", B, H, W, fps, stride, F);
+  NNUE_REQUIRE(fps * 28 * 4 <= 64 * 1024, NNUE_E_SHAPE, "nnue_ftm_conv_binarize: fps=%d too large for the LDS weight tile", fps);
+  const int Gh = (H - 1) / stride + 1, Gw = (W - 1) / stride + 1;
+  const long long G = (long long)Gh * Gw;
+  NNUE_REQUIRE(G * fps < (1ll << 30) && (long long)B * G * fps < (1ll << 40), NNUE_E_SHAPE, "nnue_ftm_conv_binarize: map too large");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int threads = G <= 64 ? 64 : (G <= 128 ? 128 : 256);
+  // one workgroup per sample when the batch alone fills the chip; otherwise split samples (at least one position per
+  // thread and slice) until there are about two workgroups per CU
+  int slices = (512 + B - 1) / B;
+  if (slices > (int)(G / threads)) slices = (int)(G / threads);
+  slices = slices < 1 ? 1 : (slices > 16 ? 16 : slices);
+  if (slices > 1) {
+    if (hipMemsetAsync(n, 0, (size_t)B * sizeof(int), s) != hipSuccess || hipMemsetAsync(sink, 0, (size_t)B * sizeof(float), s) != hipSuccess) {
+      (void)hipGetLastError();
+      nnue_set_error("nnue_ftm_conv_binarize: clearing the per-sample counters failed");
+      return NNUE_E_LAUNCH;
+    }
+  }
+  hipLaunchKernelGGL(conv_binarize_kernel, dim3(B, slices), dim3(threads), fps * 28 * sizeof(float), s, images, weight, thr, conv_out, bits, n,
+                     sink, H, W, fps, stride, Gh, Gw, F, slices);
+  return nnue_launch_status("nnue_ftm_conv_binarize");
 }
 
 extern "C" int nnue_binarize_features(const float* conv_out, const float* thr, int B, int fps, int Gh, int Gw, int F,

@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -48,6 +48,7 @@ SIGNATURES = {
     "nnue_ftm_supported": (_c_int, [_c_int, _c_int, _c_int]),
     "nnue_ftm_scratch": (_c_i64, [_c_int, _c_int, _c_int, _c_int]),
     "nnue_ftm_binarize": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p]),
+    "nnue_ftm_conv_binarize": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "nnue_ftm_forward": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_i64, _c_p]),
     "nnue_ftm_backward_weight": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
     "nnue_ftm_backward_values": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p]),
@@ -510,6 +511,32 @@ def ftm_binarize(conv_out: torch.Tensor, thr: torch.Tensor, num_rows: int, l1: i
     _call("nnue_ftm_binarize", conv_out.data_ptr(), thr.data_ptr(), b, fps, gh, gw, int(num_rows), fm.bits.data_ptr(),
           fm.n.data_ptr(), fm.sink.data_ptr(), _stream(conv_out))
     return fm
+
+
+def ftm_conv_binarize(images: torch.Tensor, weight: torch.Tensor, thr: torch.Tensor, stride: int, num_rows: int, l1: int,
+                      conv_out: Optional[torch.Tensor] = None, fm: Optional[FeatureMatrix] = None):
+    """conv3x3_forward + ftm_binarize in one launch; returns (conv_out, fm), bitwise the two separate calls."""
+    images = _need(images, torch.float32, "images")
+    if images.dim() != 4 or images.shape[1] != 3:
+        raise ValueError(f"images: expected [B,3,H,W], got {tuple(images.shape)}")
+    b, _, h, w = images.shape
+    weight = _need(weight, torch.float32, "conv.weight")
+    fps = weight.shape[0]
+    if tuple(weight.shape) != (fps, 3, 3, 3):
+        raise ValueError("conv.weight: expected [fps,3,3,3]")
+    thr = _need(thr.reshape(-1), torch.float32, "threshold", (fps,))
+    gh, gw = conv_out_hw(h, w, stride)
+    if conv_out is None:
+        conv_out = torch.empty((b, fps, gh, gw), dtype=torch.float32, device=images.device)
+    elif tuple(conv_out.shape) != (b, fps, gh, gw):
+        raise ValueError("ftm_conv_binarize: conv_out has the wrong shape")
+    if fm is None:
+        fm = FeatureMatrix.empty(b, fps * gh * gw, num_rows, l1, images.device)
+    elif fm.batch != b or fm.positions != fps * gh * gw or fm.num_rows != num_rows:
+        raise ValueError("ftm_conv_binarize: buffers do not match the map")
+    _call("nnue_ftm_conv_binarize", images.data_ptr(), weight.data_ptr(), thr.data_ptr(), b, h, w, fps, int(stride), int(num_rows),
+          conv_out.data_ptr(), fm.bits.data_ptr(), fm.n.data_ptr(), fm.sink.data_ptr(), _stream(images))
+    return conv_out, fm
 
 
 def ftm_forward(weight: torch.Tensor, bias: torch.Tensor, fm: FeatureMatrix, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -223,10 +223,12 @@ class NnueTrainer:
     def _segment(self, name: str) -> None:
         p, g = self.p, self.g
         if name == "front":
+            if self.use_mfma:  # conv + {0,1} map + counts in one launch
+                lib.ftm_conv_binarize(self.images, p["conv.weight"], p["visual_threshold"], self.stride, self.F, self.L1,
+                                      conv_out=self.conv_out, fm=self.fm)
+                return
             lib.conv3x3_forward(self.images, p["conv.weight"], self.stride, out=self.conv_out)
-            if self.use_mfma:
-                lib.ftm_binarize(self.conv_out, p["visual_threshold"], self.F, self.L1, fm=self.fm)
-            elif self.use_bits:
+            if self.use_bits:
                 lib.binarize_bits(self.conv_out, p["visual_threshold"], self.F, self.L1, bits=self.bits, stages=1)
             else:
                 lib.binarize_features(self.conv_out, p["visual_threshold"], self.F, act=self.act)
@@ -240,7 +242,7 @@ class NnueTrainer:
                 lib.ftb_forward(p["input.weight"], p["input.bias"], self.bits, out=self.ft)
             else:
                 lib.ft_forward(p["input.weight"], p["input.bias"], self.act, out=self.ft)
-            self._cls_step(1)
+            self._cls_step(5)  # + the first-layer weight product beside d_x
         elif name == "ft_wgrad":
             if self.use_mfma and self.merge_backward:
                 # weight gradient, value gradient and tail rows share one launch (independent work, all read d_ft)
@@ -253,7 +255,7 @@ class NnueTrainer:
             else:
                 lib.ft_backward_weight(self.d_ft, self.act, self.F, d_weight=g["input.weight"], d_bias=g["input.bias"])
         elif name == "cls_wgrad":
-            self._cls_step(2)
+            self._cls_step(6)
         elif name == "tail":
             if self.use_mfma and self.merge_backward:
                 pass  # d_conv_out came out of the merged launch in "ft_wgrad"

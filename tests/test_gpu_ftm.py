@@ -149,3 +149,22 @@ def test_merged_backward_is_bitwise_the_two_launches(hip, shape):
     d_v = hip.ftm_backward_values(d_out, weight, fm)
     m_w, m_b, m_v = hip.ftm_backward(d_out, weight, fm)
     assert torch.equal(m_w, d_w) and torch.equal(m_b, d_b) and torch.equal(m_v, d_v)
+
+
+@pytest.mark.parametrize("shape", [(512, 32, 32, 8, 3, 800), (128, 224, 224, 64, 7, 65536), (5, 17, 23, 4, 2, 300), (3, 96, 96, 8, 10, 800),
+                                   (2, 40, 40, 12, 1, 100)])
+def test_conv_binarize_is_bitwise_the_two_calls(hip, shape):
+    b, h, w, fps, stride, f = shape
+    gen = torch.Generator().manual_seed(h + fps)
+    images = torch.randn(b, 3, h, w, generator=gen).to(DEV)
+    weight = (torch.randn(fps, 3, 3, 3, generator=gen) * 0.2).to(DEV)
+    thr = (torch.randn(fps, generator=gen) * 0.1).to(DEV)
+    conv_ref = hip.conv3x3_forward(images, weight, stride)
+    if conv_ref[0].numel() % 4:
+        pytest.skip("map size not a multiple of 4")
+    fm_ref = hip.ftm_binarize(conv_ref, thr, f, 64)
+    conv, fm = hip.ftm_conv_binarize(images, weight, thr, stride, f, 64)
+    assert torch.equal(conv, conv_ref) and torch.equal(fm.bits, fm_ref.bits)
+    assert torch.equal(fm.n, fm_ref.n) and torch.equal(fm.sink, fm_ref.sink)
+    again = hip.ftm_conv_binarize(images, weight, thr, stride, f, 64, conv_out=conv, fm=fm)
+    assert torch.equal(again[1].n, fm_ref.n)  # counters are re-zeroed when a sample is split over slices

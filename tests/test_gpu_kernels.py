@@ -309,3 +309,31 @@ def test_classifier_train_step_equals_separate_calls(hip, shape, clip):
     ref_loss, _ = orc.cross_entropy_backward(orc.classifier_forward(orc.pairwise(x.cpu().double()), *[t.cpu().double() for t in p],
                                                                     clip=clip if clip > 0 else None), labels.cpu())
     assert abs(float(floss) - float(ref_loss)) <= 1e-4 * max(1.0, abs(float(ref_loss)))
+
+
+@pytest.mark.parametrize("shape", [(512, 1024, 128, 32, 10), (100, 1024, 128, 32, 1000), (33, 256, 48, 16, 7), (5, 24, 7, 5, 3)])
+def test_classifier_train_step_phase_splits_are_identical(hip, shape):
+    """phases 3 (one call), 1 then 2, 5 then 6 (first-layer weight product inside the d_x launch) and 7: same bits."""
+    b, l1, l2, l3, c = shape
+    gen = torch.Generator().manual_seed(sum(shape))
+    x = g(torch.randn(b, l1, generator=gen))
+    mk = lambda *s: torch.randn(*s, generator=gen) / (s[-1] ** 0.5)  # noqa: E731
+    p = [g(t) for t in (mk(l2, l1), mk(l2) * 0.1, mk(l3, l2), mk(l3) * 0.1, mk(c, l3), mk(c) * 0.1)]
+    labels = g(torch.randint(0, c, (b,), generator=gen))
+
+    def run(sequence):
+        scratch = torch.empty((hip.classifier_train_scratch_bytes(b, l1, l2, l3, c),), dtype=torch.uint8, device=DEV)
+        keep = None
+        for ph in sequence:
+            keep = hip.classifier_train_step(x, True, *p, labels, 0.5, 0.0, scratch=scratch, phases=ph,
+                                             **({} if keep is None else dict(out=keep[0], loss_out=keep[1], d_x=keep[2], grads=keep[3])))
+        return keep
+
+    ref = run((3,))
+    for seq in ((1, 2), (5, 6), (7,)):
+        got = run(seq)
+        assert torch.equal(got[2], ref[2]) and torch.equal(got[1][1], ref[1][1]) and torch.equal(got[0][2], ref[0][2]), seq
+        for a, r in zip(got[3], ref[3]):
+            assert torch.equal(a, r), seq
+    with pytest.raises(hip.NnueHipError):
+        hip.classifier_train_step(x, True, *p, labels, phases=4)
