@@ -357,13 +357,14 @@ __global__ __launch_bounds__(256) void l1_backward_x_mfma(const float* __restric
 }
 
 // d_x and the d_w1 slabs in one launch: both only need d_z1, so the two small products share the chip instead of
-// running back to back.  Blocks [0, x_blocks) form d_x, the rest the weight-gradient slabs.
+// running back to back.  Blocks [0, w_blocks) form the weight-gradient slabs (the longer product, dispatched first),
+// the rest d_x.
 __global__ __launch_bounds__(256) void l1_backward_xw_mfma(const float* __restrict__ x, int pairwise,
                                                            const float* __restrict__ w1, const float* __restrict__ d_z1,
-                                                           int B, int L1, int L2, float* __restrict__ d_x, int x_blocks,
+                                                           int B, int L1, int L2, float* __restrict__ d_x, int w_blocks,
                                                            int ksplit, int klen, float* __restrict__ part) {
-  if ((int)blockIdx.x < x_blocks) l1_backward_x_body(x, pairwise, w1, d_z1, B, L1, L2, d_x, blockIdx.x);
-  else l1_backward_w_body(x, pairwise, d_z1, B, L1, L2, ksplit, klen, part, (long long)blockIdx.x - x_blocks);
+  if ((int)blockIdx.x < w_blocks) l1_backward_w_body(x, pairwise, d_z1, B, L1, L2, ksplit, klen, part, blockIdx.x);
+  else l1_backward_x_body(x, pairwise, w1, d_z1, B, L1, L2, d_x, (long long)blockIdx.x - w_blocks);
 }
 
 // ------------------------------------------------------------------ narrow layers (per sample, LDS)
@@ -835,9 +836,9 @@ extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const fl
     if (d_x) {
       if (p.bwx_mfma && early_bww) {
         const long long xw = (long long)((B + 15) / 16) * (L1 / 32), ww = (long long)(L2 / 32) * (L1 / 64) * p.bww_ksplit;
-        const int x_blocks = (int)((xw + 3) / 4);
-        hipLaunchKernelGGL(l1_backward_xw_mfma, dim3((unsigned)(x_blocks + (ww + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1, L2,
-                           d_x, x_blocks, p.bww_ksplit, p.bww_klen, slab_pass ? slabs : d_w1);
+        const int w_blocks = (int)((ww + 3) / 4);
+        hipLaunchKernelGGL(l1_backward_xw_mfma, dim3((unsigned)(w_blocks + (xw + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1, L2,
+                           d_x, w_blocks, p.bww_ksplit, p.bww_klen, slab_pass ? slabs : d_w1);
       } else if (p.bwx_mfma) {
         const long long waves = (long long)((B + 15) / 16) * (L1 / 32);
         hipLaunchKernelGGL(l1_backward_x_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1, L2, d_x);

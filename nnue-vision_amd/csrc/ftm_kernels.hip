@@ -305,8 +305,8 @@ __device__ __forceinline__ void tail_rows_block(const TailRows& t, int bx, int b
 __global__ __launch_bounds__(256) void ftm_tail_rows_kernel(TailRows t) { tail_rows_block(t, blockIdx.x, blockIdx.y); }
 
 // Weight gradient, value gradient and the tail rows in ONE launch: they are independent (all three read d_out), so
-// their workgroups share the chip instead of queueing behind two kernel boundaries.  Blocks [0, n_w) are weight-gradient
-// tiles, [n_w, n_w + n_v) value-gradient tiles, the rest tail-row blocks.
+// their workgroups share the chip instead of queueing behind two kernel boundaries.  Blocks [0, n_v) are value-gradient
+// tiles, [n_v, n_v + n_w) weight-gradient tiles, the rest tail-row blocks.
 template <int WM, int WN, int WK, int VM, int VN, int VK>
 __global__ __launch_bounds__(256) void ftm_backward_kernel(Mat wa, Mat wb, BwwEpi we, int wM, int wN, int wK, int w_tiles_n, int n_w,
                                                            Mat va, Mat vb, ValEpi ve, int vM, int vN, int vK, int v_tiles_n, int n_v,
@@ -314,10 +314,10 @@ __global__ __launch_bounds__(256) void ftm_backward_kernel(Mat wa, Mat wb, BwwEp
   constexpr int kW = gemm_lds_floats<WM, WN, WK, false, false>(), kV = gemm_lds_floats<VM, VN, VK, true, true>();
   __shared__ __attribute__((aligned(16))) float smem[kW > kV ? kW : kV];
   const int blk = blockIdx.x;
-  if (blk < n_w) {
-    gemm_tile<WM, WN, WK, false, false, BwwEpi>(smem, wa, wb, we, wM, wN, wK, wK + WK, w_tiles_n, blk, 0);
-  } else if (blk < n_w + n_v) {
-    gemm_tile<VM, VN, VK, true, true, ValEpi>(smem, va, vb, ve, vM, vN, vK, vK + VK, v_tiles_n, blk - n_w, 0);
+  if (blk < n_v) {  // the longer tiles (K = L1) are dispatched first
+    gemm_tile<VM, VN, VK, true, true, ValEpi>(smem, va, vb, ve, vM, vN, vK, vK + VK, v_tiles_n, blk, 0);
+  } else if (blk < n_v + n_w) {
+    gemm_tile<WM, WN, WK, false, false, BwwEpi>(smem, wa, wb, we, wM, wN, wK, wK + WK, w_tiles_n, blk - n_v, 0);
   } else {
     const int i = blk - n_w - n_v;
     tail_rows_block(t, i % t.col_blocks, i / t.col_blocks);

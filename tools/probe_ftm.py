@@ -25,6 +25,7 @@ for _ in range(20):
     lib.ftm_forward(weight, bias, fm, out)
     lib.ftm_backward_weight(d_out, fm, dw, db)
     lib.ftm_backward_values(d_out, weight, fm, dv)
+    lib.ftm_backward(d_out, weight, fm, dw, db, dv)
     if do_gather:
         lib.ftb_forward(weight, bias, bits, out)
         lib.ftb_backward_weight(d_out, bits, dw, db)
