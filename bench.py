@@ -217,6 +217,11 @@ def main():
         for name, v in kernels.items():
             if want and name.startswith(want[0]) and want[1] in name:
                 return {"bytes": v["hbm_bytes_corrected"], "l2_hit_rate": v["l2_hit_rate"], "source": f"profiles/{files[-1].name}"}
+        if entry == "nnue_ftm_backward":  # two launches at this shape: weight-gradient + value-gradient kernels
+            parts = [v for name, v in kernels.items() if name.startswith("ftm_gemm_kernel") and ("BwwEpi" in name or "ValEpi" in name)]
+            if len(parts) == 2:
+                return {"bytes": sum(v["hbm_bytes_corrected"] for v in parts), "l2_hit_rate": None,
+                        "source": f"profiles/{files[-1].name} (sum of the two launches)"}
         return None
 
     dom = max(alg, key=lambda k: dur_us[k])
