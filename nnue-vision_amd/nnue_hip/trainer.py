@@ -15,10 +15,12 @@ SGD step) is one fixed sequence of HIP kernels here, working on preallocated buf
   a hipGraph and replayed (the C ABI launches on torch's current stream);
 * data parallel = each rank takes an equal slice of the global batch; mean-loss gradients are summed
   by the all-reduce and scaled by 1/world inside the SGD kernel, where the *global* gradient norm is
-  clipped -- every rank therefore applies the identical update.  The flat buffer is reduced in two
-  buckets: everything except the threshold / conv-weight gradients (99.98 % of the bytes) is ready
-  once the FT weight gradient is done and is all-reduced WHILE the value-gradient and STE/conv
-  backward kernels run; only the 232-float tail bucket is exposed.
+  clipped -- every rank therefore applies the identical update.  Default: ONE all-reduce of the whole
+  flat gradient buffer after the local step (the value gradient now leaves in the same launch as the
+  weight gradient, so only ~16 us of STE kernels could still hide a first bucket -- less than a second
+  collective costs).  NNUE_DP_BUCKETS=2 keeps the earlier split: everything except the threshold /
+  conv-weight gradients (99.98 % of the bytes) is all-reduced while the STE/conv backward kernels run,
+  the 232-float tail bucket follows.
 
 ``FlatLayout`` and ``DataParallel`` are device-agnostic plumbing (covered by gloo tests on CPU);
 ``NnueTrainer`` is GPU-only.
@@ -86,6 +88,7 @@ class DataParallel:
         # NNUE_DP_FORCE_COLLECTIVES=1 keeps the bucketed all-reduce path on even with one rank (rehearses the
         # RCCL + hipGraph interplay on a single-GPU box; a 1-rank all-reduce is the identity)
         self.collectives = self.enabled and (self.world > 1 or os.environ.get("NNUE_DP_FORCE_COLLECTIVES") == "1")
+        self.buckets = 2 if os.environ.get("NNUE_DP_BUCKETS", "1") == "2" else 1
 
     @property
     def grad_scale(self) -> float:
@@ -405,7 +408,8 @@ class NnueTrainer:
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         graphs = self.use_graph and timers is None
 
-        parts = ("a", "b") if self.dp.collectives else ("all",)
+        two_buckets = self.dp.collectives and self.dp.buckets == 2
+        parts = ("a", "b") if two_buckets else ("all",)
         main = torch.cuda.current_stream(self.dev)
         if graphs:  # capture everything this step replays before any collective is enqueued
             for part in parts:
@@ -423,9 +427,13 @@ class NnueTrainer:
 
         if not self.dp.collectives:
             run("all")
+        elif not two_buckets:
+            # one message: the whole flat gradient buffer, after the local graph; the wait is a stream dependency
+            run("all")
+            self.dp.allreduce_sum(self.flat_grads, async_op=True).wait()
         else:
             # big bucket is complete after part a: its all-reduce runs on the collective's own stream while part b
-            # (value gradient + STE/conv backward) still computes; the tail bucket follows part b
+            # (STE/conv backward) still computes; the tail bucket follows part b
             run("a")
             big = self.dp.allreduce_sum(self.flat_grads[self.bucket_split:], async_op=True)
             run("b")

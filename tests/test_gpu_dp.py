@@ -31,16 +31,16 @@ def _build():
     return nnue.NNUE(nnue.GridFeatureSet(CFG["grid"], CFG["fps"]), CFG["l1"], CFG["l2"], CFG["l3"], num_classes=CFG["classes"]).to("cuda")
 
 
-def _worker(rank, port, out_dir, use_graph):
+def _worker(rank, port, out_dir, use_graph, buckets):
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", NNUE_DP_BUCKETS=str(buckets))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     try:
         model = _build()
         from nnue_hip.trainer import NnueTrainer
         tr = NnueTrainer(model, GLOBAL_BATCH // WORLD, (32, 32), use_graph=use_graph, input_slots=2, **OPT)
-        assert tr.dp.world == WORLD and tr.bucket_split == 8 + 8 * 27
+        assert tr.dp.world == WORLD and tr.bucket_split == 8 + 8 * 27 and tr.dp.buckets == buckets
         sl = tr.dp.shard(GLOBAL_BATCH)
         losses = []
         for s in range(STEPS):
@@ -52,12 +52,13 @@ def _worker(rank, port, out_dir, use_graph):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("buckets", (1, 2))
 @pytest.mark.parametrize("use_graph", (False, True))
-def test_two_ranks_match_single_process(tmp_path, use_graph):
+def test_two_ranks_match_single_process(tmp_path, use_graph, buckets):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(port, str(tmp_path), use_graph), nprocs=WORLD, join=True)
+    mp.spawn(_worker, args=(port, str(tmp_path), use_graph, buckets), nprocs=WORLD, join=True)
     r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
     r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
     assert torch.equal(r0["flat"], r1["flat"]), "replicas diverged"
