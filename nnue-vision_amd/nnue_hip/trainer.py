@@ -425,6 +425,16 @@ class NnueTrainer:
             else:
                 self._run_local(slot, part, main, branch=False, timers=timers)
 
+        if graphs and not self.dp.collectives and not first and ragged is None:
+            # single rank, steady state: local step + update are ONE graph (one replay per step)
+            if (slot, "full") not in self._g_local:
+                def full(st):
+                    self._run_local(slot, "all", st, branch=self.branch)
+                    lib.run_plan(upd, st.cuda_stream)
+                self._g_local[(slot, "full")] = self._capture(full)
+            self._g_local[(slot, "full")].replay()
+            self.steps_done += 1
+            return self.loss
         if not self.dp.collectives:
             run("all")
         elif not two_buckets:
