@@ -512,7 +512,8 @@ __global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restric
 // then back through the two narrow layers to d_z2 and d_z1.  Replaces tail_forward + cross_entropy +
 // tail_backward (three launches and two round trips of logits / d_logits through memory).
 // Dot products use 4 threads per output (coalesced 16-byte runs of each weight row).
-__device__ __forceinline__ float block_reduce_128(float v, bool is_max, float* red) {
+template <int NT>
+__device__ __forceinline__ float block_reduce_nt(float v, bool is_max, float* red) {  // red: NT / 64 floats
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) {
     const float o = __shfl_xor(v, s);
@@ -520,22 +521,28 @@ __device__ __forceinline__ float block_reduce_128(float v, bool is_max, float* r
   }
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  const float r = is_max ? fmaxf(red[0], red[1]) : red[0] + red[1];
+  float r = red[0];
+#pragma unroll
+  for (int i = 1; i < NT / 64; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
   __syncthreads();
   return r;
 }
 
-__global__ __launch_bounds__(128) void tail_train_kernel(const float* __restrict__ part, int ksplit,
-                                                         const float* __restrict__ b1, const float* __restrict__ w2,
-                                                         const float* __restrict__ b2, const float* __restrict__ w3,
-                                                         const float* __restrict__ b3, float clip,
-                                                         const int64_t* __restrict__ labels, float scale_over_b, int B,
-                                                         int L2, int L3, int C, float* __restrict__ h1,
-                                                         float* __restrict__ h2, float* __restrict__ logits,
-                                                         float* __restrict__ sample_loss, float* __restrict__ d_logits,
-                                                         float* __restrict__ d_z1, float* __restrict__ d_z2) {
-  extern __shared__ float lds[];  // h1 [L2] | h2 [L3] | logits / d_logits [C] | d_z2 [L3] | red [2]
-  __shared__ float part_s[4][32];
+// NT threads per sample: 128 for the usual class counts, 512 when C is large (1000 classes at 224x224: the logits,
+// the softmax and the d_z2 sum are then 4x wider per pass).
+template <int NT>
+__global__ __launch_bounds__(NT) void tail_train_kernel(const float* __restrict__ part, int ksplit,
+                                                        const float* __restrict__ b1, const float* __restrict__ w2,
+                                                        const float* __restrict__ b2, const float* __restrict__ w3,
+                                                        const float* __restrict__ b3, float clip,
+                                                        const int64_t* __restrict__ labels, float scale_over_b, int B,
+                                                        int L2, int L3, int C, float* __restrict__ h1,
+                                                        float* __restrict__ h2, float* __restrict__ logits,
+                                                        float* __restrict__ sample_loss, float* __restrict__ d_logits,
+                                                        float* __restrict__ d_z1, float* __restrict__ d_z2) {
+  extern __shared__ float lds[];  // h1 [L2] | h2 [L3] | logits / d_logits [C] | d_z2 [L3] | red [8]
+  constexpr int S = NT / 32;      // class slices of the d_z2 sum
+  __shared__ float part_s[S][32];
   float* h1s = lds;
   float* h2s = h1s + L2;
   float* lgs = h2s + L3;
@@ -543,7 +550,7 @@ __global__ __launch_bounds__(128) void tail_train_kernel(const float* __restrict
   float* red = dz2s + L3;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int og = tid >> 2, part4 = tid & 3;
-  for (int j = tid; j < L2; j += 128) {
+  for (int j = tid; j < L2; j += NT) {
     float z = b1[j];
     for (int s = 0; s < ksplit; ++s) z += part[((size_t)s * B + b) * L2 + j];
     const float h = act_fn(z, clip);
@@ -551,7 +558,7 @@ __global__ __launch_bounds__(128) void tail_train_kernel(const float* __restrict
     h1[(size_t)b * L2 + j] = h;
   }
   __syncthreads();
-  for (int j0 = 0; j0 < L3; j0 += 32) {
+  for (int j0 = 0; j0 < L3; j0 += NT / 4) {
     const int j = j0 + og;
     float z = 0.f;
     if (j < L3) {
@@ -567,7 +574,7 @@ __global__ __launch_bounds__(128) void tail_train_kernel(const float* __restrict
     }
   }
   __syncthreads();
-  for (int c0 = 0; c0 < C; c0 += 32) {
+  for (int c0 = 0; c0 < C; c0 += NT / 4) {
     const int c = c0 + og;
     float z = 0.f;
     if (c < C) {
@@ -585,23 +592,23 @@ __global__ __launch_bounds__(128) void tail_train_kernel(const float* __restrict
   __syncthreads();
   // softmax cross-entropy of this sample and its gradient
   float mx = -INFINITY;
-  for (int c = tid; c < C; c += 128) mx = fmaxf(mx, lgs[c]);
-  mx = block_reduce_128(mx, true, red);
+  for (int c = tid; c < C; c += NT) mx = fmaxf(mx, lgs[c]);
+  mx = block_reduce_nt<NT>(mx, true, red);
   float se = 0.f;
-  for (int c = tid; c < C; c += 128) se += expf(lgs[c] - mx);
-  se = block_reduce_128(se, false, red);
+  for (int c = tid; c < C; c += NT) se += expf(lgs[c] - mx);
+  se = block_reduce_nt<NT>(se, false, red);
   const int64_t y = labels[b];
   const bool ok = y >= 0 && y < C;
   if (tid == 0) sample_loss[b] = ok ? (mx + logf(se)) - lgs[y] : 0.0f;
   const float inv = 1.0f / se;
   __syncthreads();  // every thread has read lgs[y] / the logits it needs before they are overwritten
-  for (int c = tid; c < C; c += 128) {
+  for (int c = tid; c < C; c += NT) {
     const float g = ok ? (expf(lgs[c] - mx) * inv - (c == y ? 1.0f : 0.0f)) * scale_over_b : 0.0f;
     lgs[c] = g;
     d_logits[(size_t)b * C + c] = g;
   }
   __syncthreads();
-  // d_z2[j] = sum_c d_logits[c] w3[c][j]: 32 units x 4 class slices per pass, four independent chains per thread
+  // d_z2[j] = sum_c d_logits[c] w3[c][j]: 32 units x S class slices per pass, four independent chains per thread
   // (a single serial chain over C = 1000 classes cost 60 us of the 224x224 configuration's step)
   for (int j0 = 0; j0 < L3; j0 += 32) {
     const int j = j0 + (tid & 31), cp = tid >> 5;
@@ -609,24 +616,31 @@ __global__ __launch_bounds__(128) void tail_train_kernel(const float* __restrict
     if (j < L3) {
       const float* __restrict__ wc = w3 + j;
       int c = cp;
-      for (; c + 12 < C; c += 16) {
+      for (; c + 3 * S < C; c += 4 * S) {
         s0 = fmaf(lgs[c], wc[(size_t)c * L3], s0);
-        s1 = fmaf(lgs[c + 4], wc[(size_t)(c + 4) * L3], s1);
-        s2 = fmaf(lgs[c + 8], wc[(size_t)(c + 8) * L3], s2);
-        s3 = fmaf(lgs[c + 12], wc[(size_t)(c + 12) * L3], s3);
+        s1 = fmaf(lgs[c + S], wc[(size_t)(c + S) * L3], s1);
+        s2 = fmaf(lgs[c + 2 * S], wc[(size_t)(c + 2 * S) * L3], s2);
+        s3 = fmaf(lgs[c + 3 * S], wc[(size_t)(c + 3 * S) * L3], s3);
       }
-      for (; c < C; c += 4) s0 = fmaf(lgs[c], wc[(size_t)c * L3], s0);
+      for (; c < C; c += S) s0 = fmaf(lgs[c], wc[(size_t)c * L3], s0);
     }
     part_s[cp][tid & 31] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (cp == 0 && j < L3) {
-      const float v = ((part_s[0][tid] + part_s[1][tid]) + (part_s[2][tid] + part_s[3][tid])) * gate_fn(h2s[j], clip);
+      float q[S];
+#pragma unroll
+      for (int i = 0; i < S; ++i) q[i] = part_s[i][tid];
+#pragma unroll
+      for (int w = 1; w < S; w *= 2)  // fixed pairwise tree: (p0 + p1) + (p2 + p3) ...
+#pragma unroll
+        for (int i = 0; i + w < S; i += 2 * w) q[i] += q[i + w];
+      const float v = q[0] * gate_fn(h2s[j], clip);
       dz2s[j] = v;
       d_z2[(size_t)b * L3 + j] = v;
     }
     __syncthreads();
   }
-  for (int k = tid; k < L2; k += 128) {
+  for (int k = tid; k < L2; k += NT) {
     float s = 0.f;
     for (int j = 0; j < L3; ++j) s = fmaf(dz2s[j], w2[(size_t)j * L2 + k], s);
     d_z1[(size_t)b * L2 + k] = s * gate_fn(h1s[k], clip);
@@ -807,7 +821,7 @@ extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const fl
   NNUE_REQUIRE(B > 0 && L1 > 0 && L2 > 0 && L3 > 0 && C > 0, NNUE_E_ARG,
                "nnue_classifier_train_step: B=%d L1=%d L2=%d L3=%d C=%d must be positive", B, L1, L2, L3, C);
   NNUE_REQUIRE(!pairwise || L1 % 2 == 0, NNUE_E_SHAPE, "nnue_classifier_train_step: pairwise needs an even L1 (got %d)", L1);
-  const int64_t tail_lds = ((int64_t)L2 + 2 * L3 + C + 2) * 4;
+  const int64_t tail_lds = ((int64_t)L2 + 2 * L3 + C + 8) * 4;
   NNUE_REQUIRE(tail_lds <= 64 * 1024, NNUE_E_SHAPE, "nnue_classifier_train_step: L2+2*L3+C too large for the LDS tail");
   const ClsPlan p = make_plan(B, L1, L2, pairwise);
   const TrainLayout t = train_layout(p, B, L1, L2, L3, C);
@@ -831,8 +845,12 @@ extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const fl
       const long long waves = (long long)B * L2;
       hipLaunchKernelGGL(l1_forward_simple, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, B, L1, L2, part);
     }
-    hipLaunchKernelGGL(tail_train_kernel, dim3(B), dim3(128), (size_t)tail_lds, s, part, p.fwd_ksplit, b1, w2, b2, w3, b3, clip, labels,
-                       grad_scale / (float)B, B, L2, L3, C, h1, h2, logits, sample_loss, d_logits, d_z1, d_z2);
+    if (C > 256)
+      hipLaunchKernelGGL(tail_train_kernel<512>, dim3(B), dim3(512), (size_t)tail_lds, s, part, p.fwd_ksplit, b1, w2, b2, w3, b3, clip, labels,
+                         grad_scale / (float)B, B, L2, L3, C, h1, h2, logits, sample_loss, d_logits, d_z1, d_z2);
+    else
+      hipLaunchKernelGGL(tail_train_kernel<128>, dim3(B), dim3(128), (size_t)tail_lds, s, part, p.fwd_ksplit, b1, w2, b2, w3, b3, clip, labels,
+                         grad_scale / (float)B, B, L2, L3, C, h1, h2, logits, sample_loss, d_logits, d_z1, d_z2);
     if (d_x) {
       if (p.bwx_mfma && early_bww) {
         const long long xw = (long long)((B + 15) / 16) * (L1 / 32), ww = (long long)(L2 / 32) * (L1 / 64) * p.bww_ksplit;
