@@ -455,8 +455,9 @@ constexpr int kIntMax = 0x7fffffff;
 
 // =============================================================================== C ABI
 extern "C" int nnue_ftm_supported(int F, int P, int L1) {
-  // 16-byte staging along positions and along table columns
-  return F > 0 && P > 0 && P % 4 == 0 && L1 > 0 && L1 % 4 == 0;
+  // 16-byte staging along positions and along table columns; 32-bit byte offsets into the table (tile overhang included)
+  const long long lim = (1ll << 31) - 1;
+  return F > 0 && P > 0 && P % 4 == 0 && L1 > 0 && L1 % 4 == 0 && ((long long)F + 256) * L1 * 4 < lim && ((long long)P + 256) * L1 * 4 < lim;
 }
 
 extern "C" int64_t nnue_ftm_scratch(int B, int F, int P, int L1) {

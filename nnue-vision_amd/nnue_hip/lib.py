@@ -377,7 +377,7 @@ def ftb_supported(l1: int) -> bool:
     return bool(load().nnue_ftb_supported(int(l1)))
 
 
-def ft_path(num_rows: int, positions: int, l1: int) -> str:
+def ft_path(num_rows: int, positions: int, l1: int, batch: int = 1) -> str:
     """Which FeatureTransformer kernels the fused path uses for the binary map: "mfma" | "bits" | "list".
 
     "mfma" = dense f32-MFMA products over the float {0,1} map (fastest at the reference's ~43 % density and still
@@ -385,7 +385,9 @@ def ft_path(num_rows: int, positions: int, l1: int) -> str:
     gather kernels (any shape).  NNUE_FT_PATH=mfma|bits|list forces one where the shape allows it; the default
     takes the first of mfma, bits, list that supports the shape."""
     mode = os.environ.get("NNUE_FT_PATH", "auto")
-    can_mfma, can_bits = ftm_supported(num_rows, positions, l1), ftb_supported(l1)
+    # the product kernels address every operand with 32-bit byte offsets (batch-sized ones included)
+    fits = (batch + 256) * positions * 4 < 2 ** 31 and (batch + 256) * l1 * 4 < 2 ** 31
+    can_mfma, can_bits = fits and ftm_supported(num_rows, positions, l1), ftb_supported(l1)
     if mode == "list":
         return "list"
     if mode == "bits":

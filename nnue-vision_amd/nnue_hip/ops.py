@@ -63,7 +63,7 @@ class NnueFn(torch.autograd.Function):
         images = images.contiguous()
         conv_out = lib.conv3x3_forward(images, conv_w, stride)
         # binary features: dense MFMA products over the float map, else bit masks + LDS-staged tiles, else id lists
-        ctx.path = lib.ft_path(ft_w.shape[0], conv_out[0].numel(), ft_w.shape[1])
+        ctx.path = lib.ft_path(ft_w.shape[0], conv_out[0].numel(), ft_w.shape[1], conv_out.shape[0])
         if ctx.path == "mfma":
             feats = lib.ftm_binarize(conv_out, thr, ft_w.shape[0], ft_w.shape[1])
             ft = lib.ftm_forward(ft_w, ft_b, feats)

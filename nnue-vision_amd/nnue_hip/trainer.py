@@ -167,7 +167,7 @@ class NnueTrainer:
         self.conv_out = torch.empty((B, self.fps, self.gh, self.gw), **f32)
         # binary features: float {0,1} map + dense MFMA products when the shape allows, else bit masks + LDS-staged
         # gather kernels, else id lists
-        self.ft_path = lib.ft_path(self.F, self.P, self.L1)
+        self.ft_path = lib.ft_path(self.F, self.P, self.L1, B)
         self.use_mfma, self.use_bits = self.ft_path == "mfma", self.ft_path == "bits"
         self.fm = lib.FeatureMatrix.empty(B, self.P, self.F, self.L1, self.dev) if self.use_mfma else None
         self.bits = lib.FeatureBits.empty(B, self.P, self.F, self.L1, self.dev) if self.use_bits else None

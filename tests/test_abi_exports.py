@@ -76,3 +76,17 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(lib, "LIB_PATH", tmp_path / "libnnue_hip.so")
     with pytest.raises(lib.NnueHipError, match="no CPU or eager fallback"):
         lib.load()
+
+
+def test_feature_transformer_path_policy(monkeypatch):
+    """mfma > bits > list by shape; a shape the product kernels cannot address falls back instead of failing."""
+    monkeypatch.delenv("NNUE_FT_PATH", raising=False)
+    assert lib.ft_path(800, 968, 1024, 512) == "mfma" and lib.ft_path(65536, 65536, 1024, 128) == "mfma"
+    assert lib.ft_path(800, 27 * 5, 1024, 8) == "bits"        # map size not a multiple of 4
+    assert lib.ft_path(800, 968, 100, 8) == "mfma" and lib.ft_path(800, 27 * 5, 100, 8) == "list"  # width the LDS gather kernels lack
+    assert lib.ft_path(600000, 65536, 1024, 8) == "bits"      # table beyond 32-bit byte offsets
+    assert lib.ft_path(800, 968, 1024, 600000) == "bits"      # batch beyond 32-bit byte offsets into the map
+    monkeypatch.setenv("NNUE_FT_PATH", "bits")
+    assert lib.ft_path(800, 968, 1024, 512) == "bits"
+    monkeypatch.setenv("NNUE_FT_PATH", "list")
+    assert lib.ft_path(800, 968, 1024, 512) == "list"
