@@ -55,6 +55,8 @@ def parse():
                          "default: the reference's 0.1 threshold (~0.43)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather-compare", action="store_true",
+                    help="skip the second pass with the LDS-staged gather kernels (NNUE_FT_PATH=bits) and its HBM-roofline object")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
     return ap.parse_args()
 
@@ -249,6 +251,68 @@ def main():
                     "regime": ("table %.1f MB is L2/Infinity-Cache resident: algorithmic rate is cache bandwidth and may exceed the HBM peak"
                                % table_mb) if table_mb < 200 else "table %.0f MB exceeds the Infinity Cache: HBM-bound" % table_mb}
 
+    # ---- the same step with the LDS-staged gather kernels (the form SURVEY 8d prices against the HBM roofline), same
+    # process, same synthetic batches: images/s and the algorithmic-byte rate of its dominant FT kernel
+    gather = None
+    if world == 1 and trainer.ft_path == "mfma" and not args.no_gather_compare and os.environ.get("NNUE_FT_PATH", "auto") == "auto":
+        os.environ["NNUE_FT_PATH"] = "bits"
+        try:
+            torch.manual_seed(0)
+            model_g = nnue.NNUE(nnue.GridFeatureSet(cfg["grid"], cfg["fps"]), cfg["l1"], cfg["l2"], cfg["l3"],
+                                num_classes=cfg["classes"], input_size=cfg["image"]).to(dev)
+            if args.density is not None:
+                with torch.no_grad():
+                    model_g.visual_threshold.copy_(model.visual_threshold)
+            tg = NnueTrainer(model_g, B, (cfg["image"], cfg["image"]), group=None, use_graph=not args.no_graph, input_slots=SLOTS, **OPT)
+            if tg.ft_path == "bits":
+                for (gi, gl), (si, sl) in zip(tg.inputs, trainer.inputs):
+                    gi.copy_(si)
+                    gl.copy_(sl)
+                gsteps = max(10, min(args.steps, 100))
+                for i in range(max(5, min(args.warmup, 20))):
+                    tg.step(slot=i % SLOTS)
+                torch.cuda.synchronize(dev)
+                tg0 = time.perf_counter()
+                for i in range(gsteps):
+                    tg.step(slot=i % SLOTS)
+                torch.cuda.synchronize(dev)
+                g_elapsed = time.perf_counter() - tg0
+                gn_mean, _ = tg.active_stats()
+                gnames = ["nnue_ftb_forward", "nnue_ftb_backward_weight", "nnue_ftb_backward_values"]
+                gt = {k: [] for k in gnames}
+                for i in range(3):
+                    tg.step(slot=i % SLOTS, timers={k: [] for k in gnames})
+                gi_steps = max(5, min(30, gsteps))
+                for i in range(gi_steps):
+                    tg.step(slot=i % SLOTS, timers=gt)
+                torch.cuda.synchronize(dev)
+                gdur = {k: sum(a.elapsed_time(b) * 1e3 for a, b in v) / gi_steps for k, v in gt.items()}
+                galg = {"nnue_ftb_forward": (gn_mean + 1) * row * B, "nnue_ftb_backward_values": (gn_mean + 1) * row * B,
+                        "nnue_ftb_backward_weight": gn_mean * row * B}
+                gdom = max(galg, key=lambda k: gdur[k])
+                grate = galg[gdom] / (gdur[gdom] * 1e-6) / 1e9 if gdur[gdom] > 0 else 0.0
+                old = sorted((ROOT / "profiles").glob("r01g_pmc_traffic.json"))
+                gtraffic = None
+                if old and args.workload == "c2":
+                    kk = json.loads(old[-1].read_text())["kernels"]
+                    pat = {"nnue_ftb_forward": ("ftb_gather_kernel", ", 0,"), "nnue_ftb_backward_weight": ("ftb_gather_kernel", ", 1,"),
+                           "nnue_ftb_backward_values": ("ftb_values_kernel", "")}[gdom]
+                    for name, v in kk.items():
+                        if name.startswith(pat[0]) and pat[1] in name:
+                            gtraffic = v["hbm_bytes_corrected"]
+                gather = {"path": "NNUE_FT_PATH=bits (LDS-staged gather kernels, ftb_kernels.hip)",
+                          "images_per_sec": round(B * gsteps / g_elapsed, 1), "ms_per_step": round(g_elapsed * 1e3 / gsteps, 4),
+                          "roofline": {"bound": "hbm", "kernel": gdom, "achieved": round(grate, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": round(grate / HBM_PEAK_GBS, 4), "traffic": gtraffic,
+                                       "alg_bytes_per_launch": int(galg[gdom]), "avg_launch_us": round(gdur[gdom], 2),
+                                       "regime": ("table %.1f MB is L2/Infinity-Cache resident: algorithmic rate is cache bandwidth and may "
+                                                  "exceed the HBM peak" % table_mb) if table_mb < 200 else
+                                                 "table %.0f MB exceeds the Infinity Cache: HBM-bound" % table_mb},
+                          "kernels_us": {k: round(v, 2) for k, v in gdur.items()}}
+            del tg, model_g
+        finally:
+            os.environ["NNUE_FT_PATH"] = "auto"
+
     if rank == 0:
         out = {
             "metric": "NNUE training images/sec (full step: fwd+bwd+clip+SGD)",
@@ -273,6 +337,8 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
         }
+        if gather is not None:
+            out["gather_path"] = gather
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
         sys.stdout.flush()
