@@ -168,3 +168,35 @@ def test_conv_binarize_is_bitwise_the_two_calls(hip, shape):
     assert torch.equal(fm.n, fm_ref.n) and torch.equal(fm.sink, fm_ref.sink)
     again = hip.ftm_conv_binarize(images, weight, thr, stride, f, 64, conv_out=conv, fm=fm)
     assert torch.equal(again[1].n, fm_ref.n)  # counters are re-zeroed when a sample is split over slices
+
+
+def test_random_shapes_sweep(hip):
+    """Twenty random shapes (ragged batch, table larger / smaller than the map, odd widths): every product-form entry
+    point against the float64 restatement, and the merged launch against the separate ones."""
+    rng = torch.Generator().manual_seed(2025)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng))  # noqa: E731
+    done = 0
+    while done < 20:
+        b, fps, gh, gw = ri(1, 200), ri(1, 12), ri(1, 9), ri(1, 9)
+        p = fps * gh * gw
+        if p % 4:
+            continue
+        f = max(1, p + ri(-p // 2, p // 2))
+        l1 = 4 * ri(1, 80)
+        conv_out = torch.randn(b, fps, gh, gw, generator=rng)
+        thr = torch.randn(fps, generator=rng) * 0.3
+        weight, bias = torch.randn(f, l1, generator=rng) * 0.1, torch.randn(l1, generator=rng)
+        d_out = torch.randn(b, l1, generator=rng) / b
+        ref_out, ref_dw, ref_db, ref_dval, ref_n, ref_sink = dense_reference(conv_out, thr, weight, bias, d_out)
+        g = lambda t: t.to(DEV)  # noqa: E731
+        fm = hip.ftm_binarize(g(conv_out), g(thr), f, l1)
+        tag = (b, fps, gh, gw, f, l1)
+        assert torch.equal(fm.n.cpu(), ref_n) and torch.equal(fm.sink.cpu(), ref_sink), tag
+        assert_close_logits(hip.ftm_forward(g(weight), g(bias), fm), ref_out, f"out {tag}", rtol=2e-5)
+        d_w, d_b, d_v = hip.ftm_backward(g(d_out), g(weight), fm)
+        assert_close_grad(d_w, ref_dw, f"d_weight {tag}", rtol=2e-5)
+        assert_close_grad(d_b, ref_db, f"d_bias {tag}", rtol=2e-5)
+        assert_close_grad(d_v.view(conv_out.shape), ref_dval, f"d_conv_out {tag}", rtol=2e-5)
+        s_w, s_b = hip.ftm_backward_weight(g(d_out), fm)
+        assert torch.equal(s_w, d_w) and torch.equal(s_b, d_b) and torch.equal(hip.ftm_backward_values(g(d_out), g(weight), fm), d_v), tag
+        done += 1
