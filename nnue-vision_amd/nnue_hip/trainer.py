@@ -440,7 +440,12 @@ class NnueTrainer:
         elif not two_buckets:
             # one message: the whole flat gradient buffer, after the local graph; the wait is a stream dependency
             run("all")
-            self.dp.allreduce_sum(self.flat_grads, async_op=True).wait()
+            # a blocking (for the stream, not the host) collective: measured 25 us/step cheaper than async_op + wait()
+            # in the 1-rank RCCL rehearsal (0.1395 vs 0.1643 ms); NNUE_DP_ASYNC_OP=1 restores the latter
+            if os.environ.get("NNUE_DP_ASYNC_OP") == "1":
+                self.dp.allreduce_sum(self.flat_grads, async_op=True).wait()
+            else:
+                self.dp.allreduce_sum(self.flat_grads, async_op=False)
         else:
             # big bucket is complete after part a: its all-reduce runs on the collective's own stream while part b
             # (STE/conv backward) still computes; the tail bucket follows part b
