@@ -565,7 +565,18 @@ extern "C" int nnue_ftm_backward(const float* bits, const float* sink, const flo
   const Shape sw = plan(direct > 0 ? direct : 1, L1, B, false, false), sv = plan(B, P, L1, true, false);
   // measured: one launch wins where the products are launch-sized (C2 -10 %, C3 -8 % of the two launches) and loses
   // 7 % at the 224x224 shapes, where each product fills the chip by itself and the two tile shapes fight over L2
-  const bool pair_ok = sw.cfg == 0 && (sv.cfg == 0 || sv.cfg == 1);
+  // Tile shapes for the shared launch.  The products sit on the L2 -> LDS fill rate at these sizes (32x64 tiles: 10.7
+  // flop per staged byte, ~65 TF at ~6.8 TB/s of fills), so 64x64x64 tiles (16 flop/B) are taken for both as soon as the
+  // two products together still give ~1.75 workgroups per CU (C3: 45.5 vs 49.3 us); below that the small tiles win
+  // (C2: 28 vs 37 us).
+  static const int force_pair = env_int("NNUE_FTM_BWD_PAIR", 0);  // developer knob: 11 forces 64x64x64, 1 forbids it
+  Shape sw2 = sw, sv2 = sv;
+  for (Shape* q : {&sw2, &sv2}) { q->cfg = 1; q->bm = 64; q->bn = 64; q->bk = 64; }
+  sw2.tiles_m = (direct + 63) / 64; sw2.tiles_n = (L1 + 63) / 64; sv2.tiles_m = (B + 63) / 64; sv2.tiles_n = (P + 63) / 64;
+  const long long tiles64 = (long long)sw2.tiles_m * sw2.tiles_n + (long long)sv2.tiles_m * sv2.tiles_n;
+  const bool small_pair = sw.cfg == 0 && (sv.cfg == 0 || sv.cfg == 1);
+  const bool big_pair = force_pair == 11 || (force_pair != 1 && small_pair && tiles64 >= 448);
+  const bool pair_ok = small_pair || big_pair;
   if (direct <= 0 || !pair_ok || split_launch) {
     const int rc = nnue_ftm_backward_weight(bits, sink, d_out, B, F, P, L1, d_weight, d_bias, stream);
     return rc != NNUE_OK ? rc : nnue_ftm_backward_values(bits, d_out, weight, B, F, P, L1, d_conv_out, stream);
@@ -575,12 +586,15 @@ extern "C" int nnue_ftm_backward(const float* bits, const float* sink, const flo
   const BwwEpi we{d_weight, L1};
   const ValEpi ve{bits, d_conv_out, P};
   const TailRows t = tail_rows(d_out, sink, B, L1, direct, F, d_weight, d_bias);
-  const int n_w = sw.tiles_m * sw.tiles_n, n_v = sv.tiles_m * sv.tiles_n, n_t = t.col_blocks * (1 + t.zero_slices);
+  const Shape& swr = big_pair ? sw2 : sw;
+  const Shape& svr = big_pair ? sv2 : sv;
+  const int n_w = swr.tiles_m * swr.tiles_n, n_v = svr.tiles_m * svr.tiles_n, n_t = t.col_blocks * (1 + t.zero_slices);
   const dim3 grid((unsigned)(n_w + n_v + n_t));
 #define NNUE_FTM_BWD(WM, WN, WK, VM, VN, VK)                                                                                          \
-  hipLaunchKernelGGL((ftm_backward_kernel<WM, WN, WK, VM, VN, VK>), grid, dim3(256), 0, st, wa, wb, we, direct, L1, B, sw.tiles_n, n_w, va, \
-                     vb, ve, B, P, L1, sv.tiles_n, n_v, t)
-  if (sv.cfg == 0) NNUE_FTM_BWD(32, 64, 128, 32, 64, 128);
+  hipLaunchKernelGGL((ftm_backward_kernel<WM, WN, WK, VM, VN, VK>), grid, dim3(256), 0, st, wa, wb, we, direct, L1, B, swr.tiles_n, n_w, va, \
+                     vb, ve, B, P, L1, svr.tiles_n, n_v, t)
+  if (big_pair) NNUE_FTM_BWD(64, 64, 64, 64, 64, 64);
+  else if (sv.cfg == 0) NNUE_FTM_BWD(32, 64, 128, 32, 64, 128);
   else NNUE_FTM_BWD(32, 64, 128, 64, 64, 64);
 #undef NNUE_FTM_BWD
   return nnue_launch_status("nnue_ftm_backward");
