@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 12
+#define NNUE_HIP_ABI_VERSION 13
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -178,44 +178,44 @@ int nnue_ftb_backward_values(const float* d_out, const float* weight, const uint
  *     out      = A W + bias,   d_weight = A^T d_out,   d_value = (d_out W^T) . A
  * with A[b][f] = membership of table row f in sample b are dense enough to run as matrix products
  * (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate; summation order differs from the gather
- * kernels).  A is the binary map itself as a float {0,1} matrix bits[B][P] (P = fps*Gh*Gw, nnue.py:19-25);
- * no masks or id lists are built.  sink[b] = number of active positions >= F-1 (they clamp to row F-1,
+ * kernels).  A is the binary map itself as a byte {0,1} matrix bits[B][P] (P = fps*Gh*Gw, nnue.py:19-25),
+ * widened to float while tiles are staged; no masks or id lists are built.  sink[b] = number of active positions >= F-1 (they clamp to row F-1,
  * nnue.py:701), a rank-one term.  P and L1 must be multiples of 4 (nnue_ftm_supported). */
 int nnue_ftm_supported(int F, int P, int L1);
 int64_t nnue_ftm_scratch(int B, int F, int P, int L1); /* bytes for nnue_ftm_forward (split-K slabs) */
 
-/* StraightThroughBinary.forward as a float matrix (nnue.py:19-25): bits[b,p] = conv_out[b,p] > thr[channel of p],
+/* StraightThroughBinary.forward as a byte matrix (nnue.py:19-25): bits[b,p] = conv_out[b,p] > thr[channel of p],
  * n[b] = active positions (nnue.py:603-607), sink[b] as above.  Bit-exact given conv_out. */
 int nnue_ftm_binarize(const float* conv_out, const float* thr, int B, int fps, int Gh, int Gw, int F,
-                      float* bits, int32_t* n, float* sink, nnue_stream_t stream);
+                      uint8_t* bits, int32_t* n, float* sink, nnue_stream_t stream);
 
 /* nnue_conv3x3_forward + nnue_ftm_binarize in one launch (self.conv + StraightThroughBinary.forward, nnue.py:640,
  * :646-647, :19-25): conv_out, bits, n and sink are bitwise what the two calls give. */
 int nnue_ftm_conv_binarize(const float* images, const float* weight, const float* thr, int B, int H, int W,
-                           int fps, int stride, int F, float* conv_out, float* bits, int32_t* n, float* sink,
+                           int fps, int stride, int F, float* conv_out, uint8_t* bits, int32_t* n, float* sink,
                            nnue_stream_t stream);
 
 /* FeatureTransformer.forward for the binary map (nnue.py:686-710):
  *   out[b,:] = bias + sum_{p active, p < min(F-1,P)} weight[p,:] + sink[b] * weight[F-1,:] */
-int nnue_ftm_forward(const float* bits, const float* sink, const float* weight, const float* bias,
+int nnue_ftm_forward(const uint8_t* bits, const float* sink, const float* weight, const float* bias,
                      int B, int F, int P, int L1, float* out,
                      void* scratch, int64_t scratch_bytes, nnue_stream_t stream);
 
 /* Its weight/bias gradient (autograd of nnue.py:702-708); fixed summation order, no atomics.  Rows the map
  * cannot reach are written as zero.  Either output may be NULL. */
-int nnue_ftm_backward_weight(const float* bits, const float* sink, const float* d_out,
+int nnue_ftm_backward_weight(const uint8_t* bits, const float* sink, const float* d_out,
                              int B, int F, int P, int L1, float* d_weight, float* d_bias,
                              nnue_stream_t stream);
 
 /* Its value gradient on the map (autograd of nnue.py:705-707 and :628-633; identity STE :33):
  *   d_conv_out[b,p] = active(b,p) ? < d_out[b,:], weight[min(p,F-1),:] > : 0     for every p < P */
-int nnue_ftm_backward_values(const float* bits, const float* d_out, const float* weight,
+int nnue_ftm_backward_values(const uint8_t* bits, const float* d_out, const float* weight,
                              int B, int F, int P, int L1, float* d_conv_out, nnue_stream_t stream);
 
 /* nnue_ftm_backward_weight + nnue_ftm_backward_values as ONE launch (autograd of nnue.py:702-708, :628-633): the
  * two products and the tail rows are independent, so their workgroups share the chip.  Same results, bit for bit,
  * as the two separate calls.  All three outputs are required. */
-int nnue_ftm_backward(const float* bits, const float* sink, const float* d_out, const float* weight,
+int nnue_ftm_backward(const uint8_t* bits, const float* sink, const float* d_out, const float* weight,
                       int B, int F, int P, int L1, float* d_weight, float* d_bias, float* d_conv_out,
                       nnue_stream_t stream);
 

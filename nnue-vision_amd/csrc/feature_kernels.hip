@@ -56,12 +56,12 @@ __global__ __launch_bounds__(256) void conv3x3_forward_kernel(const float* __res
 
 // Conv forward + StraightThroughBinary.forward as the float {0,1} map + per-sample counts in one launch (the
 // front of the MFMA FeatureTransformer path): same fmaf chain as conv3x3_forward_kernel, so conv_out is bitwise the
-// same; bits[b][c*G+hw] = conv_out > thr[c]; n[b] / sink[b] as nnue_ftm_binarize.  grid (B, slices): a workgroup
+// same; bits[b][c*G+hw] = conv_out > thr[c] (one byte); n[b] / sink[b] as nnue_ftm_binarize.  grid (B, slices): a workgroup
 // walks positions hw = y*T + tid, y*T + tid + slices*T, ... of one sample; with one slice per sample the counts are
 // plain stores, otherwise integer-valued atomics into host-zeroed counters (exact in any order).
 __global__ __launch_bounds__(256) void conv_binarize_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                             const float* __restrict__ thr, float* __restrict__ out,
-                                                            float* __restrict__ bits, int* __restrict__ n,
+                                                            uint8_t* __restrict__ bits, int* __restrict__ n,
                                                             float* __restrict__ sink, int H, int W, int fps, int stride,
                                                             int Gh, int Gw, int F, int slices) {
   extern __shared__ float w_lds[];  // [fps][27] | thr [fps]
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void conv_binarize_kernel(const float* __restr
           const size_t o = (size_t)b * fps * G + p;
           const bool on = acc[u] > thr_lds[c0 + u];
           out[o] = acc[u];
-          bits[o] = on ? 1.0f : 0.0f;
+          bits[o] = on ? 1 : 0;
           cnt += on;
           snk += on && p >= F - 1;
         }
@@ -431,7 +431,7 @@ extern "C" int nnue_conv3x3_forward(const float* images, const float* weight, fl
 }
 
 extern "C" int nnue_ftm_conv_binarize(const float* images, const float* weight, const float* thr, int B, int H, int W, int fps,
-                                      int stride, int F, float* conv_out, float* bits, int32_t* n, float* sink,
+                                      int stride, int F, float* conv_out, uint8_t* bits, int32_t* n, float* sink,
                                       nnue_stream_t stream) {
   NNUE_REQUIRE(images && weight && thr && conv_out && bits && n && sink, NNUE_E_ARG, "nnue_ftm_conv_binarize: null pointer");
   NNUE_REQUIRE(B > 0 && H > 0 && W > 0 && fps > 0 && stride > 0 && F > 0, NNUE_E_ARG,

@@ -8,7 +8,9 @@
 //     d_value  = (d_out W^T) . A       (autograd of nnue.py:705-707 + :628-633, masked to the active positions)
 // are genuine matrix products, so they run on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate --
 // the same arithmetic as the gather kernels, different summation order).  A is the binary map itself, written
-// once per step as a float {0,1} matrix bits[B][P] by nnue_ftm_binarize (nnue.py:19-25); no masks or id lists.
+// once per step as a byte {0,1} matrix bits[B][P] by nnue_ftm_binarize (nnue.py:19-25) and widened to float while a
+// tile is written to LDS (a quarter of the bytes through the L2 -> LDS fill path, which is what bounds the small
+// shapes); no masks or id lists.
 // Ids >= F-1 clamp to row F-1 (nnue.py:701): that row's membership is the count sink[b], a rank-one term the
 // epilogues add (forward) or a separate column reduction forms (weight gradient); rows the map cannot reach get 0.
 //
@@ -33,23 +35,39 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 // along the inner index a K tail is zeroed by `inner_k` (KC operands whose partner is not zero there).  What a tile
 // reads past N or M along the inner index is real neighbouring data; those outputs are never stored.
 struct Mat {
-  const float* p;
+  const void* p;   // float elements, or bytes for the binary map (operand A of forward / weight gradient)
   unsigned bytes;  // window of valid rows, in bytes (< 2^31)
   int ld, clamp, inner_k;
 };
 using u32x4 = __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned;
 
-__device__ __forceinline__ float4 mat_load(__amdgpu_buffer_rsrc_t rsrc, const Mat& m, int outer, int inner) {
+// The raw 16 bytes (float operand) or 4 bytes (byte operand, in .x) of (outer, inner .. inner+3).  Nothing is done to
+// the value here: widening / splitting happens when the registers are stored to LDS, one K tile later, so the load
+// stays in flight across the MFMA phase.  A K-tail mask moves the offset out of the window (range check -> zeros).
+template <bool U8>
+__device__ __forceinline__ u32x4 mat_load(__amdgpu_buffer_rsrc_t rsrc, const Mat& m, int outer, int inner) {
   const int row = outer < m.clamp ? outer : m.clamp;
-  // the K-tail mask moves the offset out of the window (the range check then returns zeros): nothing touches the
-  // loaded registers before the LDS store, so the load stays in flight across the MFMA phase
-  const int off = inner < m.inner_k ? (row * m.ld + inner) * 4 : 0x7ffffff0;
-  const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+  const int elem = row * m.ld + inner;
+  if (U8) {
+    u32x4 raw = {0u, 0u, 0u, 0u};
+    raw[0] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, inner < m.inner_k ? elem : 0x7ffffff0, 0, 0);
+    return raw;
+  }
+  return __builtin_amdgcn_raw_buffer_load_b128(rsrc, inner < m.inner_k ? elem * 4 : 0x7ffffff0, 0, 0);
+}
+
+template <bool U8>
+__device__ __forceinline__ float4 widen(const u32x4& raw) {
+  if (U8) {
+    const unsigned w = raw[0];
+    return make_float4((float)(w & 0xffu), (float)((w >> 8) & 0xffu), (float)((w >> 16) & 0xffu), (float)(w >> 24));
+  }
   return make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]), __uint_as_float(raw[3]));
 }
 
 // ---- epilogues: col(n) gives per-column values, pre(m, n) a per-element operand loaded before any store ---------
 struct FwdEpi {  // out = acc + bias + sink[b] * weight[F-1]   (or a split-K slab, finished by ftm_finish_kernel)
+  static constexpr bool kAU8 = true;  // operand A is the byte map
   const float* __restrict__ bias;
   const float* __restrict__ w_last;  // weight row F-1
   const float* __restrict__ sink;
@@ -64,6 +82,7 @@ struct FwdEpi {  // out = acc + bias + sink[b] * weight[F-1]   (or a split-K sla
 };
 
 struct BwwEpi {  // d_weight rows with a position of their own
+  static constexpr bool kAU8 = true;
   float* __restrict__ d_weight;
   int L1;
   __device__ __forceinline__ float2 col(int) const { return make_float2(0.f, 0.f); }
@@ -72,11 +91,12 @@ struct BwwEpi {  // d_weight rows with a position of their own
 };
 
 struct ValEpi {  // d_conv_out = acc where the position is active, else 0
-  const float* __restrict__ bits;
+  static constexpr bool kAU8 = false;
+  const uint8_t* __restrict__ bits;
   float* __restrict__ d_conv_out;
   int P;
   __device__ __forceinline__ float2 col(int) const { return make_float2(0.f, 0.f); }
-  __device__ __forceinline__ float pre(int m, int p) const { return bits[(size_t)m * P + p]; }
+  __device__ __forceinline__ float pre(int m, int p) const { return (float)bits[(size_t)m * P + p]; }
   __device__ __forceinline__ void store(int m, int p, float v, float2, float bit, int) const {
     d_conv_out[(size_t)m * P + p] = bit != 0.0f ? v : 0.0f;
   }
@@ -99,8 +119,9 @@ __device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& m
   // KC image: unpadded rows with the 16-byte chunk index XOR-swizzled by the row, so that every 16-lane group of a
   // fragment ds_read_b128 (16 different rows, two neighbouring chunks) lands on 16 different 16-byte slots
   auto kc = [](int row, int k) { return row * BK + ((((k >> 2) ^ (BK == 32 ? (row >> 1) & 7 : row & 15))) << 2); };
-  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ma.p), 0, ma.bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(mb.p), 0, mb.bytes, 0x00020000);
+  constexpr bool AU8 = Epi::kAU8;
+  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ma.p), 0, ma.bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(mb.p), 0, mb.bytes, 0x00020000);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
@@ -115,14 +136,14 @@ __device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& m
   auto a_k = [&](int i) { const int g = tid + 256 * i; return AKC ? (g % (BK / 4)) * 4 : g / (BM / 4); };
   auto b_row = [&](int i) { const int g = tid + 256 * i; return BKC ? g / (BK / 4) : (g % (BN / 4)) * 4; };
   auto b_k = [&](int i) { const int g = tid + 256 * i; return BKC ? (g % (BK / 4)) * 4 : g / (BN / 4); };
-  float4 ra[AG], rb[BG];
+  u32x4 ra[AG], rb[BG];
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < AG; ++i)
-      ra[i] = AKC ? mat_load(rsa, ma, m_base + a_row(i), k0 + a_k(i)) : mat_load(rsa, ma, k0 + a_k(i), m_base + a_row(i));
+      ra[i] = AKC ? mat_load<AU8>(rsa, ma, m_base + a_row(i), k0 + a_k(i)) : mat_load<AU8>(rsa, ma, k0 + a_k(i), m_base + a_row(i));
 #pragma unroll
     for (int i = 0; i < BG; ++i)
-      rb[i] = BKC ? mat_load(rsb, mb, n_base + b_row(i), k0 + b_k(i)) : mat_load(rsb, mb, k0 + b_k(i), n_base + b_row(i));
+      rb[i] = BKC ? mat_load<false>(rsb, mb, n_base + b_row(i), k0 + b_k(i)) : mat_load<false>(rsb, mb, k0 + b_k(i), n_base + b_row(i));
   };
   const int m0 = (wave >> 1) * (BM / 2), n0 = (wave & 1) * (BN / 2);
   // fragments of the 16-k block at kb: a lane supplies k = kb + 4q .. 4q+3 of row r of each of its tiles
@@ -150,9 +171,9 @@ __device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& m
   fetch(k_lo);
   for (int k0 = k_lo; k0 < k_hi; k0 += BK) {
 #pragma unroll
-    for (int i = 0; i < AG; ++i) *reinterpret_cast<float4*>(&As[AKC ? kc(a_row(i), a_k(i)) : a_k(i) * LDA + a_row(i)]) = ra[i];
+    for (int i = 0; i < AG; ++i) *reinterpret_cast<float4*>(&As[AKC ? kc(a_row(i), a_k(i)) : a_k(i) * LDA + a_row(i)]) = widen<AU8>(ra[i]);
 #pragma unroll
-    for (int i = 0; i < BG; ++i) *reinterpret_cast<float4*>(&Bs[BKC ? kc(b_row(i), b_k(i)) : b_k(i) * LDB + b_row(i)]) = rb[i];
+    for (int i = 0; i < BG; ++i) *reinterpret_cast<float4*>(&Bs[BKC ? kc(b_row(i), b_k(i)) : b_k(i) * LDB + b_row(i)]) = widen<false>(rb[i]);
     __syncthreads();
     if (k0 + BK < k_hi) fetch(k0 + BK);
     float4 a[2][TM], b[2][TN];
@@ -324,15 +345,15 @@ __global__ __launch_bounds__(256) void ftm_backward_kernel(Mat wa, Mat wb, BwwEp
   }
 }
 
-// bits[b][p] = conv_out[b][p] > thr[channel] as float, n[b] = active positions, sink[b] = active positions >= F-1.
+// bits[b][p] = conv_out[b][p] > thr[channel] as a byte, n[b] = active positions, sink[b] = active positions >= F-1.
 // grid (B, slices); integer-valued atomics into host-zeroed counters when a sample is split (exact in any order).
 __global__ __launch_bounds__(256) void ftm_binarize_kernel(const float* __restrict__ conv_out, const float* __restrict__ thr,
-                                                           int P, int G, int F, int slices, float* __restrict__ bits,
+                                                           int P, int G, int F, int slices, uint8_t* __restrict__ bits,
                                                            int* __restrict__ n, float* __restrict__ sink) {
   __shared__ int cnt_s[4], sink_s[4];
   const int b = blockIdx.x;
   const float4* __restrict__ x4 = reinterpret_cast<const float4*>(conv_out + (size_t)b * P);
-  float4* __restrict__ o4 = reinterpret_cast<float4*>(bits + (size_t)b * P);
+  unsigned* __restrict__ o4 = reinterpret_cast<unsigned*>(bits + (size_t)b * P);
   int cnt = 0, snk = 0;
   for (int g = blockIdx.y * 256 + threadIdx.x; g < P / 4; g += 256 * slices) {
     const float4 x = x4[g];
@@ -346,7 +367,7 @@ __global__ __launch_bounds__(256) void ftm_binarize_kernel(const float* __restri
     v.z = x.z > thr[c] ? 1.0f : 0.0f;
     if (++rem == G) { rem = 0; ++c; }
     v.w = x.w > thr[c] ? 1.0f : 0.0f;
-    o4[g] = v;
+    o4[g] = (unsigned)v.x | ((unsigned)v.y << 8) | ((unsigned)v.z << 16) | ((unsigned)v.w << 24);
     cnt += (int)(v.x + v.y + v.z + v.w);
     snk += (p >= F - 1 ? (int)v.x : 0) + (p + 1 >= F - 1 ? (int)v.y : 0) + (p + 2 >= F - 1 ? (int)v.z : 0) + (p + 3 >= F - 1 ? (int)v.w : 0);
   }
@@ -467,7 +488,7 @@ extern "C" int64_t nnue_ftm_scratch(int B, int F, int P, int L1) {
   return s.ksplit > 1 ? (int64_t)s.ksplit * B * L1 * (int64_t)sizeof(float) : 0;
 }
 
-extern "C" int nnue_ftm_binarize(const float* conv_out, const float* thr, int B, int fps, int Gh, int Gw, int F, float* bits,
+extern "C" int nnue_ftm_binarize(const float* conv_out, const float* thr, int B, int fps, int Gh, int Gw, int F, uint8_t* bits,
                                  int32_t* n, float* sink, nnue_stream_t stream) {
   NNUE_REQUIRE(conv_out && thr && bits && n && sink, NNUE_E_ARG, "nnue_ftm_binarize: null pointer");
   NNUE_REQUIRE(B > 0 && fps > 0 && Gh > 0 && Gw > 0 && F > 0 && (long long)fps * Gh * Gw < (1ll << 30), NNUE_E_ARG,
@@ -489,7 +510,7 @@ extern "C" int nnue_ftm_binarize(const float* conv_out, const float* thr, int B,
   return nnue_launch_status("nnue_ftm_binarize");
 }
 
-extern "C" int nnue_ftm_forward(const float* bits, const float* sink, const float* weight, const float* bias, int B, int F, int P,
+extern "C" int nnue_ftm_forward(const uint8_t* bits, const float* sink, const float* weight, const float* bias, int B, int F, int P,
                                 int L1, float* out, void* scratch, int64_t scratch_bytes, nnue_stream_t stream) {
   NNUE_REQUIRE(bits && sink && weight && bias && out, NNUE_E_ARG, "nnue_ftm_forward: null pointer");
   NNUE_REQUIRE(shape_ok(B, F, P, L1), NNUE_E_ARG, "nnue_ftm_forward: B=%d F=%d P=%d L1=%d out of range", B, F, P, L1);
@@ -506,7 +527,7 @@ extern "C" int nnue_ftm_forward(const float* bits, const float* sink, const floa
   float* dst = s.ksplit > 1 ? static_cast<float*>(scratch) : out;
   const float* w_last = weight + (size_t)(F - 1) * L1;
   // A = the map (its K tail needs no zeroing: the table window ends at row `direct`, so B is zero there)
-  launch<true, false>(st, s, Mat{bits, (unsigned)((size_t)B * P * 4), P, kIntMax, kIntMax},
+  launch<true, false>(st, s, Mat{bits, (unsigned)((size_t)B * P), P, kIntMax, kIntMax},
                       Mat{weight, (unsigned)((size_t)direct * L1 * 4), L1, kIntMax, kIntMax}, FwdEpi{bias, w_last, sink, dst, B, L1, s.ksplit}, B,
                       L1, K);
   if (s.ksplit > 1) {
@@ -517,7 +538,7 @@ extern "C" int nnue_ftm_forward(const float* bits, const float* sink, const floa
   return nnue_launch_status("nnue_ftm_forward");
 }
 
-extern "C" int nnue_ftm_backward_weight(const float* bits, const float* sink, const float* d_out, int B, int F, int P, int L1,
+extern "C" int nnue_ftm_backward_weight(const uint8_t* bits, const float* sink, const float* d_out, int B, int F, int P, int L1,
                                         float* d_weight, float* d_bias, nnue_stream_t stream) {
   NNUE_REQUIRE(bits && sink && d_out, NNUE_E_ARG, "nnue_ftm_backward_weight: null pointer");
   NNUE_REQUIRE(d_weight || d_bias, NNUE_E_ARG, "nnue_ftm_backward_weight: both outputs are null");
@@ -528,7 +549,7 @@ extern "C" int nnue_ftm_backward_weight(const float* bits, const float* sink, co
   const int direct = (F - 1 < P) ? F - 1 : P;
   if (d_weight && direct > 0) {
     const Shape s = plan(direct, L1, B, false, false);
-    launch<false, false>(st, s, Mat{bits, (unsigned)((size_t)B * P * 4), P, kIntMax, kIntMax},
+    launch<false, false>(st, s, Mat{bits, (unsigned)((size_t)B * P), P, kIntMax, kIntMax},
                          Mat{d_out, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, kIntMax}, BwwEpi{d_weight, L1}, direct, L1, B);
   }
   const TailRows t = tail_rows(d_out, sink, B, L1, direct, F, d_weight, d_bias);
@@ -536,7 +557,7 @@ extern "C" int nnue_ftm_backward_weight(const float* bits, const float* sink, co
   return nnue_launch_status("nnue_ftm_backward_weight");
 }
 
-extern "C" int nnue_ftm_backward_values(const float* bits, const float* d_out, const float* weight, int B, int F, int P, int L1,
+extern "C" int nnue_ftm_backward_values(const uint8_t* bits, const float* d_out, const float* weight, int B, int F, int P, int L1,
                                         float* d_conv_out, nnue_stream_t stream) {
   NNUE_REQUIRE(bits && d_out && weight && d_conv_out, NNUE_E_ARG, "nnue_ftm_backward_values: null pointer");
   NNUE_REQUIRE(shape_ok(B, F, P, L1), NNUE_E_ARG, "nnue_ftm_backward_values: B=%d F=%d P=%d L1=%d out of range", B, F, P, L1);
@@ -552,7 +573,7 @@ extern "C" int nnue_ftm_backward_values(const float* bits, const float* d_out, c
 
 // Both gradients of the binary-map FeatureTransformer in one launch (see ftm_backward_kernel); falls back to the two
 // separate launches for tile-shape pairs that are not instantiated.
-extern "C" int nnue_ftm_backward(const float* bits, const float* sink, const float* d_out, const float* weight, int B, int F, int P,
+extern "C" int nnue_ftm_backward(const uint8_t* bits, const float* sink, const float* d_out, const float* weight, int B, int F, int P,
                                  int L1, float* d_weight, float* d_bias, float* d_conv_out, nnue_stream_t stream) {
   NNUE_REQUIRE(bits && sink && d_out && weight && d_weight && d_bias && d_conv_out, NNUE_E_ARG, "nnue_ftm_backward: null pointer");
   NNUE_REQUIRE(shape_ok(B, F, P, L1), NNUE_E_ARG, "nnue_ftm_backward: B=%d F=%d P=%d L1=%d out of range", B, F, P, L1);
@@ -581,7 +602,7 @@ extern "C" int nnue_ftm_backward(const float* bits, const float* sink, const flo
     const int rc = nnue_ftm_backward_weight(bits, sink, d_out, B, F, P, L1, d_weight, d_bias, stream);
     return rc != NNUE_OK ? rc : nnue_ftm_backward_values(bits, d_out, weight, B, F, P, L1, d_conv_out, stream);
   }
-  const Mat wa{bits, (unsigned)((size_t)B * P * 4), P, kIntMax, kIntMax}, wb{d_out, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, kIntMax};
+  const Mat wa{bits, (unsigned)((size_t)B * P), P, kIntMax, kIntMax}, wb{d_out, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, kIntMax};
   const Mat va{d_out, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, L1}, vb{weight, (unsigned)((size_t)F * L1 * 4), L1, F - 1, kIntMax};
   const BwwEpi we{d_weight, L1};
   const ValEpi ve{bits, d_conv_out, P};

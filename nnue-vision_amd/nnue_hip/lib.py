@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -475,8 +475,8 @@ def ftm_scratch_bytes(b: int, num_rows: int, positions: int, l1: int) -> int:
 
 
 class FeatureMatrix:
-    """The binary map of one batch as a float {0,1} matrix (layout: include/nnue_hip.h, nnue_ftm_*)."""
-    bits: torch.Tensor     # float32 [B, P]
+    """The binary map of one batch as a byte {0,1} matrix (layout: include/nnue_hip.h, nnue_ftm_*)."""
+    bits: torch.Tensor     # uint8 [B, P]
     n: torch.Tensor        # int32 [B]    active positions
     sink: torch.Tensor     # float32 [B]  active positions >= F-1
     scratch: torch.Tensor  # uint8, split-K slabs of the forward
@@ -492,7 +492,7 @@ class FeatureMatrix:
 
     @staticmethod
     def empty(batch: int, positions: int, num_rows: int, l1: int, device) -> "FeatureMatrix":
-        return FeatureMatrix(torch.empty((batch, positions), dtype=torch.float32, device=device),
+        return FeatureMatrix(torch.empty((batch, positions), dtype=torch.uint8, device=device),
                              torch.empty((batch,), dtype=torch.int32, device=device),
                              torch.empty((batch,), dtype=torch.float32, device=device),
                              torch.empty((max(16, ftm_scratch_bytes(batch, num_rows, positions, l1)),), dtype=torch.uint8, device=device),

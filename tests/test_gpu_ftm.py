@@ -56,7 +56,7 @@ def test_ftm_kernels_against_float64(hip, shape, density):
     g = lambda t: t.to(DEV)
     fm = hip.ftm_binarize(g(conv_out), g(thr), f, l1)
     active = (conv_out > thr.view(1, -1, 1, 1)).reshape(b, -1)
-    assert torch.equal(fm.n.cpu(), ref_n) and torch.equal(fm.sink.cpu(), ref_sink) and torch.equal(fm.bits.cpu(), active.float())
+    assert torch.equal(fm.n.cpu(), ref_n) and torch.equal(fm.sink.cpu(), ref_sink) and torch.equal(fm.bits.cpu(), active.to(torch.uint8))
     out = hip.ftm_forward(g(weight), g(bias), fm)
     assert_close_logits(out, ref_out, "out", rtol=2e-5)
     d_w, d_b = hip.ftm_backward_weight(g(d_out), fm)
