@@ -13,6 +13,7 @@ reference.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -70,9 +71,16 @@ def compute_metrics(outputs: torch.Tensor, targets: torch.Tensor) -> Dict[str, f
 def evaluate_model(model: torch.nn.Module, loader, loss_fn=None, device: Optional[torch.device] = None
                    ) -> Tuple[float, Dict[str, float]]:
     """Mean of the per-batch mean cross-entropies and the metrics over the whole loader (evaluate.py:62-87).
-    ``loss_fn`` is accepted and ignored, exactly like the reference.  One host read-back at the end."""
+    ``loss_fn`` is accepted and ignored, exactly like the reference.  One host read-back at the end.
+
+    An NNUE on the GPU goes through a replayed hipGraph per batch shape (nnue_hip/eval_plan.py): same kernels as the
+    eager forward, no per-call Python between them; anything else takes the eager path below."""
     if device is None:
         device = next(model.parameters()).device
+    import nnue as _nnue
+    if isinstance(model, _nnue.NNUE) and torch.device(device).type == "cuda" and next(model.parameters()).is_cuda \
+            and os.environ.get("NNUE_EVAL_GRAPH", "1") != "0":
+        return _evaluate_nnue_graph(model, loader, device)
     confusion = None
     losses = []
     for images, labels in loader:
@@ -88,6 +96,25 @@ def evaluate_model(model: torch.nn.Module, loader, loss_fn=None, device: Optiona
         raise ValueError("evaluate_model: empty loader")
     total = torch.stack(losses).double().sum().item()  # the single synchronisation
     return total / len(losses), metrics_from_confusion(confusion.cpu().numpy())
+
+
+def _evaluate_nnue_graph(model, loader, device) -> Tuple[float, Dict[str, float]]:
+    from nnue_hip.eval_plan import plan_for
+    plans, batches = [], 0
+    for images, labels in loader:
+        if images.dim() != 4 or images.shape[1] != 3:
+            raise ValueError(f"images: expected [B,3,H,W], got {tuple(images.shape)}")
+        plan = plan_for(model, int(images.shape[0]), (int(images.shape[2]), int(images.shape[3])))
+        if plan not in plans:
+            plan.reset()
+            plans.append(plan)
+        plan.run(images.to(device, non_blocking=True).float(), labels.to(device, non_blocking=True).long())
+        batches += 1
+    if not batches:
+        raise ValueError("evaluate_model: empty loader")
+    total = sum(p.loss_sum for p in plans)      # per-batch means, summed in float64 on the device
+    confusion = sum(p.confusion for p in plans)
+    return float(total.item()) / batches, metrics_from_confusion(confusion.cpu().numpy())  # the single synchronisation
 
 
 def evaluate_compiled_model(model: torch.nn.Module, loader, model_type: str) -> Dict[str, float]:

@@ -70,3 +70,36 @@ def test_evaluate_model_matches_reference():
     check(metrics, z["metrics"], "evaluate_model")  # same predictions -> identical metrics
     with pytest.raises(ValueError):
         evaluate.evaluate_model(model, [], None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("classes", (10, 1))
+def test_graph_replayed_evaluation_equals_eager(monkeypatch, classes):
+    """evaluate_model's hipGraph path (one plan per batch shape, ragged last batch, weights updated in between)
+    against the eager forward: same confusion matrix, same loss."""
+    import nnue
+    torch.manual_seed(3)
+    model = nnue.NNUE(nnue.GridFeatureSet(10, 8), 256, 32, 16, num_classes=classes).cuda()
+    gen = torch.Generator().manual_seed(4)
+    sizes = [64, 64, 64, 23]
+    loader = [(torch.randn(n, 3, 32, 32, generator=gen), torch.randint(0, max(classes, 2), (n,), generator=gen)) for n in sizes]
+    results = {}
+    for mode in ("1", "0", "1"):
+        monkeypatch.setenv("NNUE_EVAL_GRAPH", mode)
+        results.setdefault(mode, []).append(evaluate.evaluate_model(model, loader))
+    (l1, m1), (l2, m2) = results["1"]  # first call captures, second replays everything
+    l0, m0 = results["0"][0]
+    for loss, metrics in ((l1, m1), (l2, m2)):
+        assert abs(loss - l0) <= 1e-12 * max(1.0, abs(l0))
+        assert metrics == m0
+    # parameters change in place between evaluations (what an optimizer step does): the plan follows
+    with torch.no_grad():
+        model.classifier.classifier[4].bias.add_(torch.randn(classes, device="cuda"))
+        model.visual_threshold.add_(0.05)
+    monkeypatch.setenv("NNUE_EVAL_GRAPH", "1")
+    la, ma = evaluate.evaluate_model(model, loader)
+    monkeypatch.setenv("NNUE_EVAL_GRAPH", "0")
+    lb, mb = evaluate.evaluate_model(model, loader)
+    assert abs(la - lb) <= 1e-12 * max(1.0, abs(lb)) and ma == mb
+    if classes > 1:
+        assert (la, ma) != (l0, m0)
