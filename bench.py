@@ -169,7 +169,8 @@ def main():
     ftp = {"mfma": "nnue_ftm", "bits": "nnue_ftb", "list": "nnue_ft"}[trainer.ft_path]
     names = (["nnue_ftm_conv_binarize"] if trainer.use_mfma else
              ["nnue_conv3x3_forward", {"bits": "nnue_binarize_bits", "list": "nnue_binarize_features"}[trainer.ft_path]])
-    names += [f"{ftp}_forward", "nnue_classifier_train_step"]
+    fwd_entry = f"{ftp}_forward_l1" if getattr(trainer, "fuse_l1", False) else f"{ftp}_forward"  # fused: + layer-1 slabs in the epilogue
+    names += [fwd_entry, "nnue_classifier_train_step"]
     # weight + value gradient (+ tail rows) go through one C call; it is one launch at launch-sized shapes and the two
     # separate launches at the 224x224 shapes (policy in nnue_ftm_backward)
     merged = trainer.use_mfma and trainer.merge_backward
@@ -198,6 +199,8 @@ def main():
     }
     if merged:
         alg = {f"{ftp}_forward": alg[f"{ftp}_forward"], f"{ftp}_backward": alg[f"{ftp}_backward_values"] + alg[f"{ftp}_backward_weight"]}
+    if fwd_entry != f"{ftp}_forward":
+        alg[fwd_entry] = alg.pop(f"{ftp}_forward")
     kernels = {k: {"avg_us": round(dur_us[k], 2), **({"alg_GBps": round(alg[k] / dur_us[k] * 1e-3, 1)} if k in alg and dur_us[k] > 0 else {})}
                for k in names}
     def pmc_traffic(entry):
@@ -211,7 +214,7 @@ def main():
         kernels = data.get("workloads", {}).get(args.workload) or (data.get("kernels") if args.workload == "c2" else None)
         if not kernels:
             return None
-        want = {"nnue_ftm_forward": ("ftm_gemm_kernel", "FwdEpi"), "nnue_ftm_backward": ("ftm_backward_kernel", ""), "nnue_ftm_backward_weight": ("ftm_gemm_kernel", "BwwEpi"),
+        want = {"nnue_ftm_forward": ("ftm_gemm_kernel", "FwdEpi"), "nnue_ftm_forward_l1": ("ftm_gemm_kernel", "FwdEpi"), "nnue_ftm_backward": ("ftm_backward_kernel", ""), "nnue_ftm_backward_weight": ("ftm_gemm_kernel", "BwwEpi"),
                 "nnue_ftm_backward_values": ("ftm_gemm_kernel", "ValEpi"),
                 "nnue_ftb_forward": ("ftb_gather_kernel", ", 0,"), "nnue_ftb_backward_weight": ("ftb_gather_kernel", ", 1,"),
                 "nnue_ftb_backward_values": ("ftb_values_kernel", ""), "nnue_ft_forward": ("ft_forward_wide", ""),
@@ -236,6 +239,7 @@ def main():
         flops = {f"{ftp}_forward": 2.0 * B * direct * cfg["l1"], f"{ftp}_backward_weight": 2.0 * B * direct * cfg["l1"],
                  f"{ftp}_backward_values": 2.0 * B * trainer.P * cfg["l1"]}
         flops[f"{ftp}_backward"] = flops[f"{ftp}_backward_weight"] + flops[f"{ftp}_backward_values"]
+        flops[f"{ftp}_forward_l1"] = flops[f"{ftp}_forward"] + 2.0 * B * cfg["l1"] * cfg["l2"]  # + the layer-1 product
         achieved = flops[dom] / (dur_us[dom] * 1e-6) / 1e12 if dur_us[dom] > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": (pmc_traffic(dom) or {}).get("bytes"),

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 13
+#define NNUE_HIP_ABI_VERSION 14
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -201,6 +201,16 @@ int nnue_ftm_forward(const uint8_t* bits, const float* sink, const float* weight
                      int B, int F, int P, int L1, float* out,
                      void* scratch, int64_t scratch_bytes, nnue_stream_t stream);
 
+int nnue_ftm_forward_l1_supported(int B, int F, int P, int L1, int L2); /* shapes nnue_ftm_forward_l1 takes */
+
+/* nnue_ftm_forward that also forms, in its epilogue, each 64-column tile's share of the pairwise block and the
+ * classifier's first Linear (nnue.py:660-666, :728-730): part[t][b][j] for t < L1/64, to be consumed by
+ * nnue_classifier_train_step with phases bit 8 (part = the start of its scratch).  out (the FeatureTransformer
+ * output) is bitwise what nnue_ftm_forward writes.  Shapes: nnue_ftm_forward_l1_supported (declared above). */
+int nnue_ftm_forward_l1(const uint8_t* bits, const float* sink, const float* weight, const float* bias,
+                        const float* w1, int B, int F, int P, int L1, int L2, float* out, float* part,
+                        nnue_stream_t stream);
+
 /* Its weight/bias gradient (autograd of nnue.py:702-708); fixed summation order, no atomics.  Rows the map
  * cannot reach are written as zero.  Either output may be NULL. */
 int nnue_ftm_backward_weight(const uint8_t* bits, const float* sink, const float* d_out,
@@ -252,7 +262,9 @@ int nnue_classifier_backward(const float* x, int pairwise,
  * and the six weight/bias gradients (needs phase 1 on the same scratch; nothing downstream waits for it, so a
  * caller may run it on a second stream), 3 = both.  Adding 4 (phases 5 then 6, or 7) moves the first-layer weight
  * product into phase 1's d_x launch -- both only need d_z1, so the two small products share the chip; the phase-2
- * call (same arguments) then only sums its slabs.  Results are identical either way.
+ * call (same arguments) then only sums its slabs.  Results are identical either way.  Adding 8 says the layer-1
+ * pre-activation slabs part[L1/64][B][L2] are already at the START of scratch, written by nnue_ftm_forward_l1 (the
+ * FeatureTransformer forward forms them in its epilogue); phase 1 then launches no layer-1 product of its own.
  * scratch >= nnue_classifier_train_scratch(B, L1, L2, L3, C) bytes. */
 int64_t nnue_classifier_train_scratch(int B, int L1, int L2, int L3, int C);
 int nnue_classifier_train_step(const float* x, int pairwise,

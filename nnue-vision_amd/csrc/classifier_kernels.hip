@@ -790,7 +790,10 @@ TrainLayout train_layout(const ClsPlan& p, int B, int L1, int L2, int L3, int C)
   TrainLayout t{};
   int64_t off = 0;
   auto take = [&](int64_t n) { const int64_t o = off; off += nnue_round_up(n, 4); return o; };
-  t.part = take((int64_t)p.fwd_ksplit * B * L2);
+  // the layer-1 slabs come from this module's own forward (fwd_ksplit of them) or from the fused FeatureTransformer
+  // forward (one per 64 columns of L1, phases bit 8): room for whichever is more
+  const int64_t ext = (L1 % 64 == 0) ? L1 / 64 : 0;
+  t.part = take((p.fwd_ksplit > ext ? (int64_t)p.fwd_ksplit : ext) * B * L2);
   t.d_z1 = take((int64_t)B * L2);
   t.d_z2 = take((int64_t)B * L3);
   t.d_logits = take((int64_t)B * C);
@@ -815,8 +818,12 @@ extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const fl
                                           void* scratch, int64_t scratch_bytes, int phases, nnue_stream_t stream) {
   NNUE_REQUIRE(x && w1 && b1 && w2 && b2 && w3 && b3 && labels && h1 && h2 && logits && sample_loss && loss && scratch,
                NNUE_E_ARG, "nnue_classifier_train_step: null pointer");
-  NNUE_REQUIRE(phases >= 1 && phases <= 7 && (phases & 3), NNUE_E_ARG,
-               "nnue_classifier_train_step: phases = 1 (activations + d_x) | 2 (weight gradients + loss) [| 4: first-layer weight product beside d_x]");
+  NNUE_REQUIRE(phases >= 1 && phases <= 15 && (phases & 3), NNUE_E_ARG,
+               "nnue_classifier_train_step: phases = 1 (activations + d_x) | 2 (weight gradients + loss) [| 4: first-layer weight product beside "
+               "d_x] [| 8: layer-1 slabs already at the start of scratch]");
+  const bool ext_slabs = (phases & 8) != 0;
+  NNUE_REQUIRE(!ext_slabs || (pairwise && L1 % 64 == 0), NNUE_E_SHAPE,
+               "nnue_classifier_train_step: phases bit 8 needs the pairwise block and L1 %% 64 == 0 (got L1=%d)", L1);
   NNUE_REQUIRE(d_w1 && d_b1 && d_w2 && d_b2 && d_w3 && d_b3, NNUE_E_ARG, "nnue_classifier_train_step: null gradient pointer");
   NNUE_REQUIRE(B > 0 && L1 > 0 && L2 > 0 && L3 > 0 && C > 0, NNUE_E_ARG,
                "nnue_classifier_train_step: B=%d L1=%d L2=%d L3=%d C=%d must be positive", B, L1, L2, L3, C);
@@ -837,8 +844,11 @@ extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const fl
   // bit 4: the d_w1 product runs in phase 1's d_x launch (both MFMA forms, d_x requested); a later phase-2 call with the
   // same bit then only sums its slabs
   const bool early_bww = (phases & 4) && p.bwx_mfma && p.bww_mfma && d_x != nullptr;
+  const int tail_slabs = ext_slabs ? L1 / 64 : p.fwd_ksplit;
   if (phases & 1) {
-    if (p.fwd_mfma) {
+    if (ext_slabs) {
+      // part[L1/64][B][L2] was written by nnue_ftm_forward_l1 (the FeatureTransformer forward's epilogue)
+    } else if (p.fwd_mfma) {
       const long long waves = (long long)((B + 15) / 16) * ((L2 + 63) / 64) * p.fwd_ksplit;
       hipLaunchKernelGGL(l1_forward_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, B, L1, L2, p.fwd_ksplit, part);
     } else {
@@ -846,10 +856,10 @@ extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const fl
       hipLaunchKernelGGL(l1_forward_simple, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, B, L1, L2, part);
     }
     if (C > 256)
-      hipLaunchKernelGGL(tail_train_kernel<512>, dim3(B), dim3(512), (size_t)tail_lds, s, part, p.fwd_ksplit, b1, w2, b2, w3, b3, clip, labels,
+      hipLaunchKernelGGL(tail_train_kernel<512>, dim3(B), dim3(512), (size_t)tail_lds, s, part, tail_slabs, b1, w2, b2, w3, b3, clip, labels,
                          grad_scale / (float)B, B, L2, L3, C, h1, h2, logits, sample_loss, d_logits, d_z1, d_z2);
     else
-      hipLaunchKernelGGL(tail_train_kernel<128>, dim3(B), dim3(128), (size_t)tail_lds, s, part, p.fwd_ksplit, b1, w2, b2, w3, b3, clip, labels,
+      hipLaunchKernelGGL(tail_train_kernel<128>, dim3(B), dim3(128), (size_t)tail_lds, s, part, tail_slabs, b1, w2, b2, w3, b3, clip, labels,
                          grad_scale / (float)B, B, L2, L3, C, h1, h2, logits, sample_loss, d_logits, d_z1, d_z2);
     if (d_x) {
       if (p.bwx_mfma && early_bww) {

@@ -68,6 +68,7 @@ __device__ __forceinline__ float4 widen(const u32x4& raw) {
 // ---- epilogues: col(n) gives per-column values, pre(m, n) a per-element operand loaded before any store ---------
 struct FwdEpi {  // out = acc + bias + sink[b] * weight[F-1]   (or a split-K slab, finished by ftm_finish_kernel)
   static constexpr bool kAU8 = true;  // operand A is the byte map
+  static constexpr bool kFusedL1 = false;
   const float* __restrict__ bias;
   const float* __restrict__ w_last;  // weight row F-1
   const float* __restrict__ sink;
@@ -83,6 +84,7 @@ struct FwdEpi {  // out = acc + bias + sink[b] * weight[F-1]   (or a split-K sla
 
 struct BwwEpi {  // d_weight rows with a position of their own
   static constexpr bool kAU8 = true;
+  static constexpr bool kFusedL1 = false;
   float* __restrict__ d_weight;
   int L1;
   __device__ __forceinline__ float2 col(int) const { return make_float2(0.f, 0.f); }
@@ -92,6 +94,7 @@ struct BwwEpi {  // d_weight rows with a position of their own
 
 struct ValEpi {  // d_conv_out = acc where the position is active, else 0
   static constexpr bool kAU8 = false;
+  static constexpr bool kFusedL1 = false;
   const uint8_t* __restrict__ bits;
   float* __restrict__ d_conv_out;
   int P;
@@ -102,10 +105,107 @@ struct ValEpi {  // d_conv_out = acc where the position is active, else 0
   }
 };
 
+// FeatureTransformer forward whose epilogue also forms this column tile's share of the classifier's first layer
+// (pairwise block nnue.py:660-666 + Linear(L1, L2) nnue.py:728-730): tile t owns table columns 32t .. 32t+31 AND
+// L1/2 + 32t .. L1/2 + 32t+31, i.e. both factors of 32 pairwise products, so it can write the slab
+//   part[t][b][j] = sum_{c<32} ft[b][32t+c] * ft[b][L1/2+32t+c] * w1[j][32t+c]  +  ft[b][32t+c] * w1[j][L1/2+32t+c]
+// that nnue_classifier_train_step otherwise gets from its own layer-1 launch (phases bit 8).
+struct FwdL1Epi {
+  static constexpr bool kAU8 = true;
+  static constexpr bool kFusedL1 = true;
+  const float* __restrict__ bias;
+  const float* __restrict__ w_last;
+  const float* __restrict__ sink;
+  float* __restrict__ out;   // ft [B][L1]
+  const float* __restrict__ w1;  // [L2][L1]
+  float* __restrict__ part;  // [L1/64][B][L2]
+  int B, L1, L2, half;
+  // table / ft column of tile-local column index n_abs = 64 * tile + n_local
+  __device__ __forceinline__ int col(int n_abs) const { return ((n_abs >> 6) << 5) + (n_abs & 31) + ((n_abs & 32) ? half : 0); }
+};
+
 // LDS floats one tile needs (both staged operands)
 template <int BM, int BN, int BK, bool AKC, bool BKC>
 constexpr int gemm_lds_floats() {
   return (AKC ? BM * BK : BK * (BM + 4)) + (BKC ? BN * BK : BK * (BN + 4));
+}
+
+// Epilogue of the fused forward (BN = 64, waves 2 x 2): ft tile -> memory and LDS, pairwise products in LDS, then the
+// [BM x 64] x [64 x L2] product on the MFMA with the w1 fragments read straight from memory (L2-resident, 32 KB per
+// workgroup).  smem: BM x 68 floats for the ft tile + BM x 68 for the l0 tile.
+constexpr int kL1Ld = 68;
+template <int BM>
+__device__ __forceinline__ void fused_l1_epilogue(const FwdL1Epi& e, float* __restrict__ smem, const f32x4 (&acc)[BM / 32][2], int m_base,
+                                                  int tile_n, int m0, int n0, int r, int q, int wave, int tid) {
+  float* __restrict__ T = smem;
+  float* __restrict__ L0 = smem + BM * kL1Ld;
+  constexpr int TM = BM / 32;
+  float sk[TM][4];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int ee = 0; ee < 4; ++ee) {
+      const int m = m_base + m0 + 16 * i + 4 * q + ee;
+      sk[i][ee] = m < e.B ? e.sink[m] : 0.0f;
+    }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int n_loc = n0 + 16 * t + r;
+    const int colg = e.col(tile_n * 64 + n_loc);
+    const float bv = e.bias[colg], wl = e.w_last[colg];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int ee = 0; ee < 4; ++ee) {
+        const int m_loc = m0 + 16 * i + 4 * q + ee, m = m_base + m_loc;
+        const float v = acc[i][t][ee] + fmaf(sk[i][ee], wl, bv);  // same arithmetic as FwdEpi
+        if (m < e.B) e.out[(size_t)m * e.L1 + colg] = v;
+        T[m_loc * kL1Ld + n_loc] = m < e.B ? v : 0.0f;
+      }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < BM * 64; idx += 256) {
+    const int m_loc = idx >> 6, c = idx & 63;
+    const float* __restrict__ row = T + m_loc * kL1Ld;
+    L0[m_loc * kL1Ld + c] = c < 32 ? row[c] * row[32 + c] : row[c - 32];
+  }
+  __syncthreads();
+  const int n_tiles = (e.L2 + 15) / 16;
+  for (int nt = wave; nt < n_tiles; nt += 4) {
+    const int j = nt * 16 + r;
+    const bool jok = j < e.L2;
+    const float* __restrict__ wrow = e.w1 + (size_t)(jok ? j : 0) * e.L1;
+    float4 bq[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const int k = kb * 16 + 4 * q;  // tile-local l0 column; 4 consecutive columns stay inside one 32-column run
+      const int colg = k < 32 ? tile_n * 32 + k : e.half + tile_n * 32 + (k - 32);
+      bq[kb] = jok ? *reinterpret_cast<const float4*>(wrow + colg) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    f32x4 z[BM / 16];
+#pragma unroll
+    for (int mt = 0; mt < BM / 16; ++mt) z[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+      for (int mt = 0; mt < BM / 16; ++mt) {
+        const float4 a = *reinterpret_cast<const float4*>(&L0[(mt * 16 + r) * kL1Ld + kb * 16 + 4 * q]);
+        z[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq[kb].x, z[mt], 0, 0, 0);
+        z[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq[kb].y, z[mt], 0, 0, 0);
+        z[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq[kb].z, z[mt], 0, 0, 0);
+        z[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq[kb].w, z[mt], 0, 0, 0);
+      }
+    }
+    if (jok) {
+#pragma unroll
+      for (int mt = 0; mt < BM / 16; ++mt)
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) {
+          const int m = m_base + mt * 16 + 4 * q + ee;
+          if (m < e.B) e.part[((size_t)tile_n * e.B + m) * e.L2 + j] = z[mt][ee];
+        }
+    }
+  }
 }
 
 // One BM x BN output tile (linear tile index `tile`, K slab `ks`) by the 256 threads of a workgroup; `smem` is the
@@ -136,6 +236,10 @@ __device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& m
   auto a_k = [&](int i) { const int g = tid + 256 * i; return AKC ? (g % (BK / 4)) * 4 : g / (BM / 4); };
   auto b_row = [&](int i) { const int g = tid + 256 * i; return BKC ? g / (BK / 4) : (g % (BN / 4)) * 4; };
   auto b_k = [&](int i) { const int g = tid + 256 * i; return BKC ? (g % (BK / 4)) * 4 : g / (BN / 4); };
+  auto b_col = [&](int n_abs) {  // fused forward: a tile's 64 columns are two 32-column runs (see FwdL1Epi)
+    if constexpr (Epi::kFusedL1) return epi.col(n_abs);
+    else return n_abs;
+  };
   u32x4 ra[AG], rb[BG];
   auto fetch = [&](int k0) {
 #pragma unroll
@@ -143,7 +247,8 @@ __device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& m
       ra[i] = AKC ? mat_load<AU8>(rsa, ma, m_base + a_row(i), k0 + a_k(i)) : mat_load<AU8>(rsa, ma, k0 + a_k(i), m_base + a_row(i));
 #pragma unroll
     for (int i = 0; i < BG; ++i)
-      rb[i] = BKC ? mat_load<false>(rsb, mb, n_base + b_row(i), k0 + b_k(i)) : mat_load<false>(rsb, mb, k0 + b_k(i), n_base + b_row(i));
+      rb[i] = BKC ? mat_load<false>(rsb, mb, n_base + b_row(i), k0 + b_k(i))
+                  : mat_load<false>(rsb, mb, k0 + b_k(i), b_col(n_base + b_row(i)));
   };
   const int m0 = (wave >> 1) * (BM / 2), n0 = (wave & 1) * (BN / 2);
   // fragments of the 16-k block at kb: a lane supplies k = kb + 4q .. 4q+3 of row r of each of its tiles
@@ -205,6 +310,10 @@ __device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& m
     }
     __syncthreads();
   }
+  if constexpr (Epi::kFusedL1) {
+    fused_l1_epilogue<BM>(epi, smem, acc, m_base, tile_n, m0, n0, r, q, wave, tid);
+    return;
+  } else {
   // accumulator register e of lane 16 q + r holds C[row 4 q + e][col r]; every epilogue operand is loaded before
   // the first store so that the loads overlap
   float2 cv[TN];
@@ -232,12 +341,20 @@ __device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& m
         if (m < M && n < N) epi.store(m, n, acc[i][t][e], cv[t], pre[i][t][e], ks);
       }
   }
+  }
 }
 
 template <int BM, int BN, int BK, bool AKC, bool BKC, class Epi>
 __global__ __launch_bounds__(256) void ftm_gemm_kernel(Mat ma, Mat mb, Epi epi, int M, int N, int K, int klen, int tiles_n) {
   __shared__ __attribute__((aligned(16))) float smem[gemm_lds_floats<BM, BN, BK, AKC, BKC>()];
   gemm_tile<BM, BN, BK, AKC, BKC, Epi>(smem, ma, mb, epi, M, N, K, klen, tiles_n, blockIdx.x, blockIdx.y);
+}
+
+template <int BM, int BK>
+__global__ __launch_bounds__(256) void ftm_forward_l1_kernel(Mat ma, Mat mb, FwdL1Epi epi, int M, int N, int K, int tiles_n) {
+  constexpr int kGemm = gemm_lds_floats<BM, 64, BK, true, false>(), kEpi = 2 * BM * kL1Ld;
+  __shared__ __attribute__((aligned(16))) float smem[kGemm > kEpi ? kGemm : kEpi];
+  gemm_tile<BM, 64, BK, true, false, FwdL1Epi>(smem, ma, mb, epi, M, N, K, K + BK, tiles_n, blockIdx.x, 0);
 }
 
 // out = bias + sink[b] * weight[F-1] + sum of the split-K slabs (fixed order)
@@ -619,4 +736,33 @@ extern "C" int nnue_ftm_backward(const uint8_t* bits, const float* sink, const f
   else NNUE_FTM_BWD(32, 64, 128, 64, 64, 64);
 #undef NNUE_FTM_BWD
   return nnue_launch_status("nnue_ftm_backward");
+}
+
+// The forward with the classifier's layer-1 slabs formed in its epilogue (FwdL1Epi).  Taken for the shapes whose
+// forward is one launch without split-K (tile 32x64x128 or 64x64x64), an even pairwise split that falls on 32-column
+// runs (L1 % 64 == 0) and float4-readable w1 rows.
+extern "C" int nnue_ftm_forward_l1_supported(int B, int F, int P, int L1, int L2) {
+  if (!nnue_ftm_supported(F, P, L1) || !shape_ok(B, F, P, L1) || L1 % 64 != 0 || L2 <= 0) return 0;
+  const int direct = (F - 1 < P) ? F - 1 : P;
+  if (direct <= 0) return 0;
+  const Shape s = plan(B, L1, direct, true, true);
+  return (s.cfg == 0 || s.cfg == 1) && s.ksplit == 1;
+}
+
+extern "C" int nnue_ftm_forward_l1(const uint8_t* bits, const float* sink, const float* weight, const float* bias, const float* w1, int B,
+                                   int F, int P, int L1, int L2, float* out, float* part, nnue_stream_t stream) {
+  NNUE_REQUIRE(bits && sink && weight && bias && w1 && out && part, NNUE_E_ARG, "nnue_ftm_forward_l1: null pointer");
+  NNUE_REQUIRE(nnue_ftm_forward_l1_supported(B, F, P, L1, L2), NNUE_E_SHAPE,
+               "nnue_ftm_forward_l1: B=%d F=%d P=%d L1=%d L2=%d is not a fused-forward shape (nnue_ftm_forward_l1_supported)", B, F, P, L1, L2);
+  NNUE_REQUIRE(nnue_aligned16(bits) && nnue_aligned16(weight) && nnue_aligned16(bias) && nnue_aligned16(out) && nnue_aligned16(w1), NNUE_E_ARG,
+               "nnue_ftm_forward_l1: pointers must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int direct = (F - 1 < P) ? F - 1 : P;
+  const Shape s = plan(B, L1, direct, true, true);
+  const Mat ma{bits, (unsigned)((size_t)B * P), P, kIntMax, kIntMax}, mb{weight, (unsigned)((size_t)direct * L1 * 4), L1, kIntMax, kIntMax};
+  const FwdL1Epi epi{bias, weight + (size_t)(F - 1) * L1, sink, out, w1, part, B, L1, L2, L1 / 2};
+  const dim3 grid((unsigned)(s.tiles_m * s.tiles_n));
+  if (s.cfg == 0) hipLaunchKernelGGL((ftm_forward_l1_kernel<32, 128>), grid, dim3(256), 0, st, ma, mb, epi, B, L1, direct, s.tiles_n);
+  else hipLaunchKernelGGL((ftm_forward_l1_kernel<64, 64>), grid, dim3(256), 0, st, ma, mb, epi, B, L1, direct, s.tiles_n);
+  return nnue_launch_status("nnue_ftm_forward_l1");
 }

@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -50,6 +50,8 @@ SIGNATURES = {
     "nnue_ftm_binarize": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p]),
     "nnue_ftm_conv_binarize": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "nnue_ftm_forward": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_i64, _c_p]),
+    "nnue_ftm_forward_l1_supported": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int]),
+    "nnue_ftm_forward_l1": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
     "nnue_ftm_backward_weight": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
     "nnue_ftm_backward_values": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p]),
     "nnue_ftm_backward": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p]),
@@ -551,6 +553,30 @@ def ftm_forward(weight: torch.Tensor, bias: torch.Tensor, fm: FeatureMatrix, out
         out = torch.empty((fm.batch, l1), dtype=torch.float32, device=weight.device)
     _call("nnue_ftm_forward", fm.bits.data_ptr(), fm.sink.data_ptr(), weight.data_ptr(), bias.data_ptr(), fm.batch, f,
           fm.positions, l1, out.data_ptr(), fm.scratch.data_ptr(), fm.scratch.numel(), _stream(weight))
+    return out
+
+
+def ftm_forward_l1_supported(batch: int, num_rows: int, positions: int, l1: int, l2: int) -> bool:
+    return bool(load().nnue_ftm_forward_l1_supported(int(batch), int(num_rows), int(positions), int(l1), int(l2)))
+
+
+def ftm_forward_l1(weight: torch.Tensor, bias: torch.Tensor, fm: FeatureMatrix, w1: torch.Tensor, part: torch.Tensor,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ftm_forward + the classifier's layer-1 slabs part[L1/64][B][L2] (written at the start of `part`, the
+    classifier's scratch buffer; consumed by classifier_train_step(phases | 8))."""
+    weight = _need(weight, torch.float32, "input.weight")
+    f, l1 = weight.shape
+    bias = _need(bias, torch.float32, "input.bias", (l1,))
+    l2 = w1.shape[0]
+    w1 = _need(w1, torch.float32, "classifier.0.weight", (l2, l1))
+    if f != fm.num_rows:
+        raise ValueError("ftm_forward_l1: the map was built for a different table")
+    if not part.is_cuda or part.numel() * part.element_size() < (l1 // 64) * fm.batch * l2 * 4:
+        raise ValueError("ftm_forward_l1: part buffer too small for [L1/64][B][L2] floats")
+    if out is None:
+        out = torch.empty((fm.batch, l1), dtype=torch.float32, device=weight.device)
+    _call("nnue_ftm_forward_l1", fm.bits.data_ptr(), fm.sink.data_ptr(), weight.data_ptr(), bias.data_ptr(), w1.data_ptr(),
+          fm.batch, f, fm.positions, l1, l2, out.data_ptr(), part.data_ptr(), _stream(weight))
     return out
 
 

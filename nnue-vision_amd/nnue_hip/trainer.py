@@ -187,6 +187,8 @@ class NnueTrainer:
                                             lib.classifier_train_scratch_bytes(B, self.L1, self.L2, self.L3, self.C)),), **u8)
         self.ste_scratch = torch.empty((max(16, lib.load().nnue_ste_conv_backward_scratch(B, self.fps, self.gh, self.gw)),), **u8)
         self.sgd_scratch = torch.empty((lib.sgd_scratch_bytes(self.layout.count),), **u8)
+        self.fuse_l1 = (self.use_mfma and os.environ.get("NNUE_FUSE_L1", "1") != "0"
+                        and lib.ftm_forward_l1_supported(B, self.F, self.P, self.L1, self.L2))
         self.steps_done = 0
         self.use_graph = use_graph
         self._g_local, self._g_update = {}, None
@@ -239,6 +241,12 @@ class NnueTrainer:
             if self.use_bits:
                 lib.binarize_bits(self.conv_out, p["visual_threshold"], self.F, self.L1, bits=self.bits, stages=2)
         elif name == "forward":
+            if self.use_mfma and self.fuse_l1:
+                # the forward's epilogue also forms the classifier's layer-1 slabs (start of its scratch)
+                lib.ftm_forward_l1(p["input.weight"], p["input.bias"], self.fm, p["classifier.classifier.0.weight"], self.cls_scratch,
+                                   out=self.ft)
+                self._cls_step(13)
+                return
             if self.use_mfma:
                 lib.ftm_forward(p["input.weight"], p["input.bias"], self.fm, out=self.ft)
             elif self.use_bits:

@@ -200,3 +200,29 @@ def test_random_shapes_sweep(hip):
         s_w, s_b = hip.ftm_backward_weight(g(d_out), fm)
         assert torch.equal(s_w, d_w) and torch.equal(s_b, d_b) and torch.equal(hip.ftm_backward_values(g(d_out), g(weight), fm), d_v), tag
         done += 1
+
+
+@pytest.mark.parametrize("shape", [(512, 8, 11, 11, 800, 1024, 128), (1024, 8, 11, 11, 800, 1024, 128), (37, 4, 8, 8, 256, 64, 32),
+                                   (130, 8, 10, 10, 800, 192, 40), (64, 8, 11, 11, 800, 256, 7)])
+def test_fused_forward_forms_the_layer1_slabs(hip, shape):
+    """nnue_ftm_forward_l1: the FeatureTransformer output is bitwise nnue_ftm_forward's, and the slabs sum to the
+    classifier's first pre-activation l0 @ w1^T (pairwise block nnue.py:660-666, Linear nnue.py:728-730)."""
+    b, fps, gh, gw, f, l1, l2 = shape
+    if not hip.ftm_forward_l1_supported(b, f, fps * gh * gw, l1, l2):
+        pytest.skip("not a fused-forward shape")
+    gen = torch.Generator().manual_seed(b + l2)
+    conv_out = torch.randn(b, fps, gh, gw, generator=gen).to(DEV)
+    thr = torch.full((fps,), 0.17).to(DEV)
+    weight, bias = (torch.randn(f, l1, generator=gen) * 0.1).to(DEV), torch.randn(l1, generator=gen).to(DEV)
+    w1 = (torch.randn(l2, l1, generator=gen) / l1 ** 0.5).to(DEV)
+    fm = hip.ftm_binarize(conv_out, thr, f, l1)
+    ref_ft = hip.ftm_forward(weight, bias, fm)
+    part = torch.full(((l1 // 64) * b * l2 + 16,), float("nan"), device=DEV)
+    ft = hip.ftm_forward_l1(weight, bias, fm, w1, part)
+    assert torch.equal(ft, ref_ft)
+    slabs = part[:(l1 // 64) * b * l2].view(l1 // 64, b, l2)
+    assert not bool(torch.isnan(slabs).any()) and bool(torch.isnan(part[(l1 // 64) * b * l2:]).all())
+    x = ref_ft.double()
+    l0 = torch.cat([x[:, :l1 // 2] * x[:, l1 // 2:], x[:, :l1 // 2]], dim=1)
+    assert_close_grad(slabs.double().sum(0), l0 @ w1.double().t(), "layer-1 pre-activation", rtol=1e-5)
+    assert not hip.ftm_forward_l1_supported(128, 65536, 65536, 1024, 128)  # split-K forward: separate layer-1 launch
