@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 14
+#define NNUE_HIP_ABI_VERSION 15
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -222,12 +222,18 @@ int nnue_ftm_backward_weight(const uint8_t* bits, const float* sink, const float
 int nnue_ftm_backward_values(const uint8_t* bits, const float* d_out, const float* weight,
                              int B, int F, int P, int L1, float* d_conv_out, nnue_stream_t stream);
 
+int nnue_ftm_backward_cw_supported(int B, int F, int P, int L1, int L2); /* shapes whose nnue_ftm_backward takes d_w1 */
+
 /* nnue_ftm_backward_weight + nnue_ftm_backward_values as ONE launch (autograd of nnue.py:702-708, :628-633): the
  * two products and the tail rows are independent, so their workgroups share the chip.  Same results, bit for bit,
- * as the two separate calls.  All three outputs are required. */
+ * as the two separate calls.  d_weight, d_bias and d_conv_out are required.
+ * Optional rider (d_w1 != NULL, shapes: nnue_ftm_backward_cw_supported, declared above): the weight gradient of the
+ * classifier's first Linear, d_w1[L2][L1] = d_z1^T l0 (autograd of nnue.py:728-730 through the pairwise block
+ * nnue.py:660-666), from ft[B][L1] (the FeatureTransformer output) and d_z1[B][L2] (left in the classifier's scratch
+ * by nnue_classifier_train_step, at nnue_classifier_train_dz1_offset); pair with phases bit 16 there. */
 int nnue_ftm_backward(const uint8_t* bits, const float* sink, const float* d_out, const float* weight,
                       int B, int F, int P, int L1, float* d_weight, float* d_bias, float* d_conv_out,
-                      nnue_stream_t stream);
+                      const float* ft, const float* d_z1, int L2, float* d_w1, nnue_stream_t stream);
 
 /* ---- pairwise product + SimpleClassifier -------------------------------------- */
 
@@ -265,8 +271,12 @@ int nnue_classifier_backward(const float* x, int pairwise,
  * call (same arguments) then only sums its slabs.  Results are identical either way.  Adding 8 says the layer-1
  * pre-activation slabs part[L1/64][B][L2] are already at the START of scratch, written by nnue_ftm_forward_l1 (the
  * FeatureTransformer forward forms them in its epilogue); phase 1 then launches no layer-1 product of its own.
+ * Adding 16 (not together with 4) says d_w1 is produced by nnue_ftm_backward's rider from the d_z1 this call leaves
+ * in scratch at byte offset nnue_classifier_train_dz1_offset (-1 for non-positive sizes): no first-layer weight
+ * product and no slab sum are launched here, d_w1 is not written.
  * scratch >= nnue_classifier_train_scratch(B, L1, L2, L3, C) bytes. */
 int64_t nnue_classifier_train_scratch(int B, int L1, int L2, int L3, int C);
+int64_t nnue_classifier_train_dz1_offset(int B, int L1, int L2, int L3, int C, int pairwise);
 int nnue_classifier_train_step(const float* x, int pairwise,
                                const float* w1, const float* b1, const float* w2, const float* b2,
                                const float* w3, const float* b3, float clip,

@@ -810,6 +810,11 @@ extern "C" int64_t nnue_classifier_train_scratch(int B, int L1, int L2, int L3, 
   return (a > b ? a : b) * (int64_t)sizeof(float);
 }
 
+extern "C" int64_t nnue_classifier_train_dz1_offset(int B, int L1, int L2, int L3, int C, int pairwise) {
+  if (B <= 0 || L1 <= 0 || L2 <= 0 || L3 <= 0 || C <= 0) return -1;
+  return train_layout(make_plan(B, L1, L2, pairwise), B, L1, L2, L3, C).d_z1 * (int64_t)sizeof(float);
+}
+
 extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const float* w1, const float* b1, const float* w2,
                                           const float* b2, const float* w3, const float* b3, float clip,
                                           const int64_t* labels, float grad_scale, int B, int L1, int L2, int L3, int C,
@@ -818,9 +823,10 @@ extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const fl
                                           void* scratch, int64_t scratch_bytes, int phases, nnue_stream_t stream) {
   NNUE_REQUIRE(x && w1 && b1 && w2 && b2 && w3 && b3 && labels && h1 && h2 && logits && sample_loss && loss && scratch,
                NNUE_E_ARG, "nnue_classifier_train_step: null pointer");
-  NNUE_REQUIRE(phases >= 1 && phases <= 15 && (phases & 3), NNUE_E_ARG,
+  NNUE_REQUIRE(phases >= 1 && phases <= 31 && (phases & 3) && (phases & 20) != 20, NNUE_E_ARG,
                "nnue_classifier_train_step: phases = 1 (activations + d_x) | 2 (weight gradients + loss) [| 4: first-layer weight product beside "
-               "d_x] [| 8: layer-1 slabs already at the start of scratch]");
+               "d_x] [| 8: layer-1 slabs already at the start of scratch] [| 16 (not with 4): d_w1 comes from nnue_ftm_backward]");
+  const bool ext_dw1 = (phases & 16) != 0;
   const bool ext_slabs = (phases & 8) != 0;
   NNUE_REQUIRE(!ext_slabs || (pairwise && L1 % 64 == 0), NNUE_E_SHAPE,
                "nnue_classifier_train_step: phases bit 8 needs the pairwise block and L1 %% 64 == 0 (got L1=%d)", L1);
@@ -877,8 +883,8 @@ extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const fl
     }
   }
   if (phases & 2) {  // needs phase 1's h1, h2, d_logits, d_z1, d_z2 (scratch) -- nothing downstream depends on it
-    if (early_bww) {
-      // the first-layer product already ran beside d_x (phases bit 4)
+    if (early_bww || ext_dw1) {
+      // the first-layer product already ran beside d_x (phases bit 4), or rides in nnue_ftm_backward's launch (bit 16)
     } else if (p.bww_mfma) {
       const long long waves = (long long)(L2 / 32) * (L1 / 64) * p.bww_ksplit;
       hipLaunchKernelGGL(l1_backward_w_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, d_z1, B, L1, L2, p.bww_ksplit,
@@ -890,10 +896,10 @@ extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const fl
     const long long outs = (long long)C * (L3 % 4 == 0 ? L3 / 4 : L3) + (long long)L3 * (L2 % 4 == 0 ? L2 / 4 : L2) + C + L3 + L2 + 1;
     const int wgrad_blocks = (int)((outs + 3) / 4);
     const long long count = (long long)L2 * L1;
-    const int slab_blocks = slab_pass ? (int)((count / 4 + 255) / 256) : 0;
+    const int slab_blocks = slab_pass && !ext_dw1 ? (int)((count / 4 + 255) / 256) : 0;
     hipLaunchKernelGGL(small_wgrad_kernel, dim3(wgrad_blocks + slab_blocks), dim3(256), 0, s, d_logits, d_z2, d_z1, h1, h2, B, L2, L3, C,
                        d_w3, d_b3, d_w2, d_b2, d_b1, (const float*)sample_loss, loss, wgrad_blocks, (const float*)slabs,
-                       slab_pass ? p.bww_ksplit : 0, count, d_w1);
+                       slab_pass && !ext_dw1 ? p.bww_ksplit : 0, count, d_w1);
   }
   return nnue_launch_status("nnue_classifier_train_step");
 }

@@ -69,6 +69,7 @@ __device__ __forceinline__ float4 widen(const u32x4& raw) {
 struct FwdEpi {  // out = acc + bias + sink[b] * weight[F-1]   (or a split-K slab, finished by ftm_finish_kernel)
   static constexpr bool kAU8 = true;  // operand A is the byte map
   static constexpr bool kFusedL1 = false;
+  static constexpr bool kBPair = false;
   const float* __restrict__ bias;
   const float* __restrict__ w_last;  // weight row F-1
   const float* __restrict__ sink;
@@ -85,6 +86,7 @@ struct FwdEpi {  // out = acc + bias + sink[b] * weight[F-1]   (or a split-K sla
 struct BwwEpi {  // d_weight rows with a position of their own
   static constexpr bool kAU8 = true;
   static constexpr bool kFusedL1 = false;
+  static constexpr bool kBPair = false;
   float* __restrict__ d_weight;
   int L1;
   __device__ __forceinline__ float2 col(int) const { return make_float2(0.f, 0.f); }
@@ -95,6 +97,7 @@ struct BwwEpi {  // d_weight rows with a position of their own
 struct ValEpi {  // d_conv_out = acc where the position is active, else 0
   static constexpr bool kAU8 = false;
   static constexpr bool kFusedL1 = false;
+  static constexpr bool kBPair = false;
   const uint8_t* __restrict__ bits;
   float* __restrict__ d_conv_out;
   int P;
@@ -105,6 +108,21 @@ struct ValEpi {  // d_conv_out = acc where the position is active, else 0
   }
 };
 
+// Weight gradient of the classifier's first Linear, d_w1 = d_z1^T l0 (autograd of nnue.py:728-730 through the pairwise
+// block nnue.py:660-666), as a third tile family of the merged backward launch: A = d_z1^T, B = l0 formed from ft while
+// its tile is stored to LDS (l0[:, c] = ft[:, c] * ft[:, c + L1/2] for c < L1/2, ft[:, c - L1/2] above; a 64-column tile
+// lies in one half because L1 % 128 == 0).
+struct CwEpi {
+  static constexpr bool kAU8 = false;
+  static constexpr bool kFusedL1 = false;
+  static constexpr bool kBPair = true;
+  float* __restrict__ d_w1;  // [L2][L1]
+  int L1, half;
+  __device__ __forceinline__ float2 col(int) const { return make_float2(0.f, 0.f); }
+  __device__ __forceinline__ float pre(int, int) const { return 0.0f; }
+  __device__ __forceinline__ void store(int m, int n, float v, float2, float, int) const { d_w1[(size_t)m * L1 + n] = v; }
+};
+
 // FeatureTransformer forward whose epilogue also forms this column tile's share of the classifier's first layer
 // (pairwise block nnue.py:660-666 + Linear(L1, L2) nnue.py:728-730): tile t owns table columns 32t .. 32t+31 AND
 // L1/2 + 32t .. L1/2 + 32t+31, i.e. both factors of 32 pairwise products, so it can write the slab
@@ -113,6 +131,7 @@ struct ValEpi {  // d_conv_out = acc where the position is active, else 0
 struct FwdL1Epi {
   static constexpr bool kAU8 = true;
   static constexpr bool kFusedL1 = true;
+  static constexpr bool kBPair = false;
   const float* __restrict__ bias;
   const float* __restrict__ w_last;
   const float* __restrict__ sink;
@@ -240,15 +259,26 @@ __device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& m
     if constexpr (Epi::kFusedL1) return epi.col(n_abs);
     else return n_abs;
   };
-  u32x4 ra[AG], rb[BG];
+  // pairwise B operand (CwEpi): the tile's columns sit in the product half (two factors) or in the copy half
+  bool b_prod = false;
+  int b_shift = 0;
+  if constexpr (Epi::kBPair) {
+    b_prod = n_base < epi.half;
+    b_shift = b_prod ? 0 : epi.half;
+  }
+  u32x4 ra[AG], rb[BG], rb2[Epi::kBPair ? BG : 1];
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < AG; ++i)
       ra[i] = AKC ? mat_load<AU8>(rsa, ma, m_base + a_row(i), k0 + a_k(i)) : mat_load<AU8>(rsa, ma, k0 + a_k(i), m_base + a_row(i));
 #pragma unroll
     for (int i = 0; i < BG; ++i)
+    {
       rb[i] = BKC ? mat_load<false>(rsb, mb, n_base + b_row(i), k0 + b_k(i))
-                  : mat_load<false>(rsb, mb, k0 + b_k(i), b_col(n_base + b_row(i)));
+                  : mat_load<false>(rsb, mb, k0 + b_k(i), b_col(n_base + b_row(i)) - b_shift);
+      if constexpr (Epi::kBPair)
+        if (b_prod) rb2[i] = mat_load<false>(rsb, mb, k0 + b_k(i), n_base + b_row(i) + epi.half);
+    }
   };
   const int m0 = (wave >> 1) * (BM / 2), n0 = (wave & 1) * (BN / 2);
   // fragments of the 16-k block at kb: a lane supplies k = kb + 4q .. 4q+3 of row r of each of its tiles
@@ -278,7 +308,15 @@ __device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& m
 #pragma unroll
     for (int i = 0; i < AG; ++i) *reinterpret_cast<float4*>(&As[AKC ? kc(a_row(i), a_k(i)) : a_k(i) * LDA + a_row(i)]) = widen<AU8>(ra[i]);
 #pragma unroll
-    for (int i = 0; i < BG; ++i) *reinterpret_cast<float4*>(&Bs[BKC ? kc(b_row(i), b_k(i)) : b_k(i) * LDB + b_row(i)]) = widen<false>(rb[i]);
+    for (int i = 0; i < BG; ++i) {
+      float4 v = widen<false>(rb[i]);
+      if constexpr (Epi::kBPair)
+        if (b_prod) {
+          const float4 w = widen<false>(rb2[i]);
+          v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w;
+        }
+      *reinterpret_cast<float4*>(&Bs[BKC ? kc(b_row(i), b_k(i)) : b_k(i) * LDB + b_row(i)]) = v;
+    }
     __syncthreads();
     if (k0 + BK < k_hi) fetch(k0 + BK);
     float4 a[2][TM], b[2][TN];
@@ -445,19 +483,29 @@ __global__ __launch_bounds__(256) void ftm_tail_rows_kernel(TailRows t) { tail_r
 // Weight gradient, value gradient and the tail rows in ONE launch: they are independent (all three read d_out), so
 // their workgroups share the chip instead of queueing behind two kernel boundaries.  Blocks [0, n_v) are value-gradient
 // tiles, [n_v, n_v + n_w) weight-gradient tiles, the rest tail-row blocks.
+struct CwArgs {  // classifier first-layer weight gradient riding in the same launch (n_c == 0: absent)
+  Mat a, b;
+  CwEpi e;
+  int M, N, K, tiles_n, n_c;
+};
+
 template <int WM, int WN, int WK, int VM, int VN, int VK>
 __global__ __launch_bounds__(256) void ftm_backward_kernel(Mat wa, Mat wb, BwwEpi we, int wM, int wN, int wK, int w_tiles_n, int n_w,
                                                            Mat va, Mat vb, ValEpi ve, int vM, int vN, int vK, int v_tiles_n, int n_v,
-                                                           TailRows t) {
+                                                           CwArgs c, TailRows t) {
   constexpr int kW = gemm_lds_floats<WM, WN, WK, false, false>(), kV = gemm_lds_floats<VM, VN, VK, true, true>();
-  __shared__ __attribute__((aligned(16))) float smem[kW > kV ? kW : kV];
+  constexpr int kC = gemm_lds_floats<32, 64, 128, false, false>();
+  constexpr int kWV = kW > kV ? kW : kV;
+  __shared__ __attribute__((aligned(16))) float smem[kWV > kC ? kWV : kC];
   const int blk = blockIdx.x;
   if (blk < n_v) {  // the longer tiles (K = L1) are dispatched first
     gemm_tile<VM, VN, VK, true, true, ValEpi>(smem, va, vb, ve, vM, vN, vK, vK + VK, v_tiles_n, blk, 0);
   } else if (blk < n_v + n_w) {
     gemm_tile<WM, WN, WK, false, false, BwwEpi>(smem, wa, wb, we, wM, wN, wK, wK + WK, w_tiles_n, blk - n_v, 0);
+  } else if (blk < n_v + n_w + c.n_c) {
+    gemm_tile<32, 64, 128, false, false, CwEpi>(smem, c.a, c.b, c.e, c.M, c.N, c.K, c.K + 128, c.tiles_n, blk - n_v - n_w, 0);
   } else {
-    const int i = blk - n_w - n_v;
+    const int i = blk - n_w - n_v - c.n_c;
     tail_rows_block(t, i % t.col_blocks, i / t.col_blocks);
   }
 }
@@ -690,32 +738,52 @@ extern "C" int nnue_ftm_backward_values(const uint8_t* bits, const float* d_out,
 
 // Both gradients of the binary-map FeatureTransformer in one launch (see ftm_backward_kernel); falls back to the two
 // separate launches for tile-shape pairs that are not instantiated.
+namespace {
+// the shape pair the merged launch is used for (also the condition for the d_w1 tile family to ride along)
+bool merged_backward_shape(int B, int F, int P, int L1, bool* big) {
+  const int direct = (F - 1 < P) ? F - 1 : P;
+  if (direct <= 0) return false;
+  static const int split_launch = env_int("NNUE_FTM_SPLIT_BACKWARD", 0);
+  static const int force_pair = env_int("NNUE_FTM_BWD_PAIR", 0);  // developer knob: 11 forces 64x64x64, 1 forbids it
+  const Shape sw = plan(direct, L1, B, false, false), sv = plan(B, P, L1, true, false);
+  const long long tiles64 = (long long)((direct + 63) / 64) * ((L1 + 63) / 64) + (long long)((B + 63) / 64) * ((P + 63) / 64);
+  const bool small_pair = sw.cfg == 0 && (sv.cfg == 0 || sv.cfg == 1);
+  *big = force_pair == 11 || (force_pair != 1 && small_pair && tiles64 >= 448);
+  return !split_launch && (small_pair || *big);
+}
+}  // namespace
+
+extern "C" int nnue_ftm_backward_cw_supported(int B, int F, int P, int L1, int L2) {
+  bool big = false;
+  return nnue_ftm_supported(F, P, L1) && shape_ok(B, F, P, L1) && merged_backward_shape(B, F, P, L1, &big) && L1 % 128 == 0 && L2 > 0 &&
+         L2 % 4 == 0 && ((long long)B + 256) * L2 * 4 < (1ll << 31);
+}
+
 extern "C" int nnue_ftm_backward(const uint8_t* bits, const float* sink, const float* d_out, const float* weight, int B, int F, int P,
-                                 int L1, float* d_weight, float* d_bias, float* d_conv_out, nnue_stream_t stream) {
+                                 int L1, float* d_weight, float* d_bias, float* d_conv_out, const float* ft, const float* d_z1, int L2,
+                                 float* d_w1, nnue_stream_t stream) {
   NNUE_REQUIRE(bits && sink && d_out && weight && d_weight && d_bias && d_conv_out, NNUE_E_ARG, "nnue_ftm_backward: null pointer");
+  const bool want_cw = d_w1 != nullptr;
+  NNUE_REQUIRE(!want_cw || (ft && d_z1 && nnue_ftm_backward_cw_supported(B, F, P, L1, L2) && nnue_aligned16(ft) && nnue_aligned16(d_z1)),
+               NNUE_E_SHAPE, "nnue_ftm_backward: d_w1 requested for a shape / pointers the merged launch does not take (nnue_ftm_backward_cw_supported)");
   NNUE_REQUIRE(shape_ok(B, F, P, L1), NNUE_E_ARG, "nnue_ftm_backward: B=%d F=%d P=%d L1=%d out of range", B, F, P, L1);
   NNUE_REQUIRE(nnue_ftm_supported(F, P, L1), NNUE_E_SHAPE, "nnue_ftm_backward: P=%d and L1=%d must be multiples of 4", P, L1);
   NNUE_REQUIRE(nnue_aligned16(bits) && nnue_aligned16(d_out) && nnue_aligned16(weight), NNUE_E_ARG,
                "nnue_ftm_backward: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int direct = (F - 1 < P) ? F - 1 : P;
-  static const int split_launch = env_int("NNUE_FTM_SPLIT_BACKWARD", 0);
   const Shape sw = plan(direct > 0 ? direct : 1, L1, B, false, false), sv = plan(B, P, L1, true, false);
   // measured: one launch wins where the products are launch-sized (C2 -10 %, C3 -8 % of the two launches) and loses
-  // 7 % at the 224x224 shapes, where each product fills the chip by itself and the two tile shapes fight over L2
-  // Tile shapes for the shared launch.  The products sit on the L2 -> LDS fill rate at these sizes (32x64 tiles: 10.7
-  // flop per staged byte, ~65 TF at ~6.8 TB/s of fills), so 64x64x64 tiles (16 flop/B) are taken for both as soon as the
-  // two products together still give ~1.75 workgroups per CU (C3: 45.5 vs 49.3 us); below that the small tiles win
-  // (C2: 28 vs 37 us).
-  static const int force_pair = env_int("NNUE_FTM_BWD_PAIR", 0);  // developer knob: 11 forces 64x64x64, 1 forbids it
+  // 7 % at the 224x224 shapes, where each product fills the chip by itself and the two tile shapes fight over L2.
+  // Tile shapes for the shared launch: the products sit near the L2 -> LDS fill rate at these sizes (32x64 tiles: 10.7
+  // flop per staged byte), so 64x64x64 tiles (16 flop/B) are taken for both as soon as the two products together still
+  // give ~1.75 workgroups per CU (C3: 45.5 vs 49.3 us); below that the small tiles win (C2: 28 vs 37 us).
+  bool big_pair = false;
+  const bool pair_ok = merged_backward_shape(B, F, P, L1, &big_pair);
   Shape sw2 = sw, sv2 = sv;
   for (Shape* q : {&sw2, &sv2}) { q->cfg = 1; q->bm = 64; q->bn = 64; q->bk = 64; }
   sw2.tiles_m = (direct + 63) / 64; sw2.tiles_n = (L1 + 63) / 64; sv2.tiles_m = (B + 63) / 64; sv2.tiles_n = (P + 63) / 64;
-  const long long tiles64 = (long long)sw2.tiles_m * sw2.tiles_n + (long long)sv2.tiles_m * sv2.tiles_n;
-  const bool small_pair = sw.cfg == 0 && (sv.cfg == 0 || sv.cfg == 1);
-  const bool big_pair = force_pair == 11 || (force_pair != 1 && small_pair && tiles64 >= 448);
-  const bool pair_ok = small_pair || big_pair;
-  if (direct <= 0 || !pair_ok || split_launch) {
+  if (!pair_ok) {
     const int rc = nnue_ftm_backward_weight(bits, sink, d_out, B, F, P, L1, d_weight, d_bias, stream);
     return rc != NNUE_OK ? rc : nnue_ftm_backward_values(bits, d_out, weight, B, F, P, L1, d_conv_out, stream);
   }
@@ -727,10 +795,18 @@ extern "C" int nnue_ftm_backward(const uint8_t* bits, const float* sink, const f
   const Shape& swr = big_pair ? sw2 : sw;
   const Shape& svr = big_pair ? sv2 : sv;
   const int n_w = swr.tiles_m * swr.tiles_n, n_v = svr.tiles_m * svr.tiles_n, n_t = t.col_blocks * (1 + t.zero_slices);
-  const dim3 grid((unsigned)(n_w + n_v + n_t));
+  CwArgs cw{};
+  if (want_cw) {  // d_w1 [L2][L1] = d_z1^T [L2 x B] l0 [B x L1]
+    cw.a = Mat{d_z1, (unsigned)((size_t)B * L2 * 4), L2, kIntMax, kIntMax};
+    cw.b = Mat{ft, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, kIntMax};
+    cw.e = CwEpi{d_w1, L1, L1 / 2};
+    cw.M = L2; cw.N = L1; cw.K = B; cw.tiles_n = (L1 + 63) / 64;
+    cw.n_c = ((L2 + 31) / 32) * cw.tiles_n;
+  }
+  const dim3 grid((unsigned)(n_w + n_v + cw.n_c + n_t));
 #define NNUE_FTM_BWD(WM, WN, WK, VM, VN, VK)                                                                                          \
   hipLaunchKernelGGL((ftm_backward_kernel<WM, WN, WK, VM, VN, VK>), grid, dim3(256), 0, st, wa, wb, we, direct, L1, B, swr.tiles_n, n_w, va, \
-                     vb, ve, B, P, L1, svr.tiles_n, n_v, t)
+                     vb, ve, B, P, L1, svr.tiles_n, n_v, cw, t)
   if (big_pair) NNUE_FTM_BWD(64, 64, 64, 64, 64, 64);
   else if (sv.cfg == 0) NNUE_FTM_BWD(32, 64, 128, 32, 64, 128);
   else NNUE_FTM_BWD(32, 64, 128, 64, 64, 64);

@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -54,7 +54,9 @@ SIGNATURES = {
     "nnue_ftm_forward_l1": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
     "nnue_ftm_backward_weight": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
     "nnue_ftm_backward_values": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p]),
-    "nnue_ftm_backward": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p]),
+    "nnue_ftm_backward_cw_supported": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int]),
+    "nnue_ftm_backward": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p,
+                                   _c_p, _c_p, _c_int, _c_p, _c_p]),
     "nnue_classifier_scratch": (_c_i64, [_c_int, _c_int, _c_int, _c_int]),
     "nnue_classifier_forward": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_f,
                                          _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p,
@@ -63,6 +65,7 @@ SIGNATURES = {
                                           _c_int, _c_int, _c_int, _c_int, _c_int,
                                           _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
     "nnue_classifier_train_scratch": (_c_i64, [_c_int, _c_int, _c_int, _c_int, _c_int]),
+    "nnue_classifier_train_dz1_offset": (_c_i64, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
     "nnue_classifier_train_step": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_f, _c_p, _c_f,
                                             _c_int, _c_int, _c_int, _c_int, _c_int,
                                             _c_p, _c_p, _c_p, _c_p, _c_p,
@@ -611,13 +614,20 @@ def ftm_backward_values(d_out: torch.Tensor, weight: torch.Tensor, fm: FeatureMa
     return dst
 
 
+def ftm_backward_cw_supported(b: int, f: int, p: int, l1: int, l2: int) -> bool:
+    """Shapes whose merged backward launch can also carry the classifier's first-layer weight gradient."""
+    return bool(load().nnue_ftm_backward_cw_supported(b, f, p, l1, l2))
+
+
 def ftm_backward(d_out: torch.Tensor, weight: torch.Tensor, fm: FeatureMatrix, d_weight: Optional[torch.Tensor] = None,
-                 d_bias: Optional[torch.Tensor] = None, dst: Optional[torch.Tensor] = None):
-    """(d_weight, d_bias, d_conv_out) in one launch; bitwise the results of ftm_backward_weight + ftm_backward_values."""
+                 d_bias: Optional[torch.Tensor] = None, dst: Optional[torch.Tensor] = None, ft: Optional[torch.Tensor] = None,
+                 d_z1: Optional[torch.Tensor] = None, d_w1: Optional[torch.Tensor] = None):
+    """(d_weight, d_bias, d_conv_out) in one launch; bitwise the results of ftm_backward_weight + ftm_backward_values.
+    With ft [B, L1], d_z1 [B, L2] and d_w1 [L2, L1] the launch also writes d_w1 = d_z1^T l0 (the pairwise block of ft)."""
     d_out = _need(d_out, torch.float32, "d_out")
     weight = _need(weight, torch.float32, "input.weight")
     b, l1 = d_out.shape
-    if tuple(weight.shape) != (fm.num_rows, l1) or b != fm.batch:
+    if weight.shape != (fm.num_rows, l1) or b != fm.batch:
         raise ValueError("ftm_backward: shape mismatch")
     if d_weight is None:
         d_weight = torch.empty((fm.num_rows, l1), dtype=torch.float32, device=d_out.device)
@@ -627,8 +637,16 @@ def ftm_backward(d_out: torch.Tensor, weight: torch.Tensor, fm: FeatureMatrix, d
         dst = torch.empty((b, fm.positions), dtype=torch.float32, device=d_out.device)
     elif dst.numel() != b * fm.positions:
         raise ValueError("ftm_backward: dst has the wrong size")
+    l2 = 0
+    if d_w1 is not None:
+        ft = _need(ft, torch.float32, "ft")
+        d_z1 = _need(d_z1, torch.float32, "d_z1")
+        l2 = d_w1.shape[0]
+        if ft.shape != (b, l1) or d_z1.numel() != b * l2 or d_w1.shape != (l2, l1) or not d_w1.is_contiguous():
+            raise ValueError("ftm_backward: ft / d_z1 / d_w1 shape mismatch")
     _call("nnue_ftm_backward", fm.bits.data_ptr(), fm.sink.data_ptr(), d_out.data_ptr(), weight.data_ptr(), b, fm.num_rows,
-          fm.positions, l1, d_weight.data_ptr(), d_bias.data_ptr(), dst.data_ptr(), _stream(d_out))
+          fm.positions, l1, d_weight.data_ptr(), d_bias.data_ptr(), dst.data_ptr(),
+          _ptr(ft if d_w1 is not None else None), _ptr(d_z1 if d_w1 is not None else None), l2, _ptr(d_w1), _stream(d_out))
     return d_weight, d_bias, dst
 
 
@@ -693,6 +711,11 @@ def classifier_backward(x, pairwise: bool, w1, w2, w3, h1, h2, d_logits, clip: f
 
 def classifier_train_scratch_bytes(b: int, l1: int, l2: int, l3: int, c: int) -> int:
     return int(load().nnue_classifier_train_scratch(b, l1, l2, l3, c))
+
+
+def classifier_train_dz1_offset(b: int, l1: int, l2: int, l3: int, c: int, pairwise: bool) -> int:
+    """Byte offset of d_z1 [B, L2] inside the classifier's training scratch (valid after phase 1)."""
+    return int(load().nnue_classifier_train_dz1_offset(b, l1, l2, l3, c, int(bool(pairwise))))
 
 
 def classifier_train_step(x, pairwise: bool, w1, b1, w2, b2, w3, b3, labels, grad_scale: float = 1.0, clip: float = 0.0,

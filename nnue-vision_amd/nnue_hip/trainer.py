@@ -202,6 +202,14 @@ class NnueTrainer:
         self.branch = os.environ.get("NNUE_GRAPH_BRANCHES", "0") == "1"
         # forked capture runs "ft_wgrad" beside "tail", which then must not depend on it
         self.merge_backward = not self.branch and os.environ.get("NNUE_FTM_SPLIT_BACKWARD", "0") != "1"
+        # the classifier's first-layer weight gradient rides in the merged FeatureTransformer backward launch (a third
+        # tile family reading d_z1 out of the classifier's scratch) where that launch is used
+        self.ride_dw1 = (self.use_mfma and self.merge_backward and os.environ.get("NNUE_FTM_RIDE_DW1", "1") != "0"
+                         and lib.ftm_backward_cw_supported(B, self.F, self.P, self.L1, self.L2))
+        self.d_z1 = None
+        if self.ride_dw1:
+            off = lib.classifier_train_dz1_offset(B, self.L1, self.L2, self.L3, self.C, True)
+            self.d_z1 = self.cls_scratch[off:off + B * self.L2 * 4].view(torch.float32).view(B, self.L2)
 
     # ------------------------------------------------------------------ kernel sequences
     def _cls_params(self):
@@ -245,7 +253,7 @@ class NnueTrainer:
                 # the forward's epilogue also forms the classifier's layer-1 slabs (start of its scratch)
                 lib.ftm_forward_l1(p["input.weight"], p["input.bias"], self.fm, p["classifier.classifier.0.weight"], self.cls_scratch,
                                    out=self.ft)
-                self._cls_step(13)
+                self._cls_step(25 if self.ride_dw1 else 13)
                 return
             if self.use_mfma:
                 lib.ftm_forward(p["input.weight"], p["input.bias"], self.fm, out=self.ft)
@@ -253,12 +261,13 @@ class NnueTrainer:
                 lib.ftb_forward(p["input.weight"], p["input.bias"], self.bits, out=self.ft)
             else:
                 lib.ft_forward(p["input.weight"], p["input.bias"], self.act, out=self.ft)
-            self._cls_step(5)  # + the first-layer weight product beside d_x
+            self._cls_step(17 if self.ride_dw1 else 5)  # 5: + the first-layer weight product beside d_x
         elif name == "ft_wgrad":
             if self.use_mfma and self.merge_backward:
                 # weight gradient, value gradient and tail rows share one launch (independent work, all read d_ft)
                 lib.ftm_backward(self.d_ft, p["input.weight"], self.fm, d_weight=g["input.weight"], d_bias=g["input.bias"],
-                                 dst=self.d_conv_out)
+                                 dst=self.d_conv_out, ft=self.ft, d_z1=self.d_z1,
+                                 d_w1=g["classifier.classifier.0.weight"] if self.ride_dw1 else None)
             elif self.use_mfma:
                 lib.ftm_backward_weight(self.d_ft, self.fm, d_weight=g["input.weight"], d_bias=g["input.bias"])
             elif self.use_bits:
@@ -266,7 +275,7 @@ class NnueTrainer:
             else:
                 lib.ft_backward_weight(self.d_ft, self.act, self.F, d_weight=g["input.weight"], d_bias=g["input.bias"])
         elif name == "cls_wgrad":
-            self._cls_step(6)
+            self._cls_step(18 if self.ride_dw1 else 6)
         elif name == "tail":
             if self.use_mfma and self.merge_backward:
                 pass  # d_conv_out came out of the merged launch in "ft_wgrad"

@@ -226,3 +226,41 @@ def test_fused_forward_forms_the_layer1_slabs(hip, shape):
     l0 = torch.cat([x[:, :l1 // 2] * x[:, l1 // 2:], x[:, :l1 // 2]], dim=1)
     assert_close_grad(slabs.double().sum(0), l0 @ w1.double().t(), "layer-1 pre-activation", rtol=1e-5)
     assert not hip.ftm_forward_l1_supported(128, 65536, 65536, 1024, 128)  # split-K forward: separate layer-1 launch
+
+
+@pytest.mark.parametrize("shape", [(512, 8, 11, 11, 800, 1024, 128), (1024, 8, 11, 11, 800, 1024, 128), (37, 4, 8, 8, 256, 128, 32),
+                                   (300, 8, 11, 11, 800, 256, 4), (64, 8, 11, 11, 2000, 384, 20)])
+def test_merged_backward_carries_the_classifier_weight_gradient(hip, shape):
+    """nnue_ftm_backward with the d_w1 rider: d_w1 = d_z1^T l0 against float64 (l0 = pairwise block of ft), and the
+    launch's own three outputs stay bitwise what they are without the rider."""
+    b, fps, gh, gw, f, l1, l2 = shape
+    assert hip.ftm_backward_cw_supported(b, f, fps * gh * gw, l1, l2)
+    gen = torch.Generator().manual_seed(b + l2)
+    conv_out = torch.randn(b, fps, gh, gw, generator=gen).to(DEV)
+    thr = torch.full((fps,), 0.3).to(DEV)
+    weight = (torch.randn(f, l1, generator=gen) * 0.1).to(DEV)
+    d_out = (torch.randn(b, l1, generator=gen) / b).to(DEV)
+    ft = torch.rand(b, l1, generator=gen).to(DEV)
+    d_z1 = (torch.randn(b, l2, generator=gen) / b).to(DEV)
+    fm = hip.ftm_binarize(conv_out, thr, f, l1)
+    m_w, m_b, m_v = hip.ftm_backward(d_out, weight, fm)
+    d_w1 = torch.full((l2, l1), float("nan"), device=DEV)
+    r_w, r_b, r_v = hip.ftm_backward(d_out, weight, fm, ft=ft, d_z1=d_z1, d_w1=d_w1)
+    assert torch.equal(m_w, r_w) and torch.equal(m_b, r_b) and torch.equal(m_v, r_v)
+    half = l1 // 2
+    ft64 = ft.double().cpu()
+    l0 = torch.cat([ft64[:, :half] * ft64[:, half:], ft64[:, :half]], dim=1)
+    ref = d_z1.double().cpu().t() @ l0
+    assert_close_grad(d_w1.cpu(), ref, "d_w1 (rider)")
+
+
+def test_rider_is_refused_where_the_launch_is_split(hip):
+    b, f, p, l1, l2 = 128, 65536, 64 * 32 * 32, 1024, 128  # C4: the two products run as separate launches
+    assert not hip.ftm_backward_cw_supported(b, f, p, l1, l2)
+    assert not hip.ftm_backward_cw_supported(512, 800, 968, 1000, 128)  # L1 % 128
+    assert not hip.ftm_backward_cw_supported(512, 800, 968, 1024, 30)  # L2 % 4
+    fm = hip.FeatureMatrix.empty(8, 968, 800, 1000, DEV)
+    fm.bits.zero_(); fm.sink.zero_(); fm.n.zero_()
+    z = lambda *s: torch.zeros(*s, device=DEV)  # noqa: E731
+    with pytest.raises(hip.NnueHipError):
+        hip.ftm_backward(z(8, 1000), z(800, 1000), fm, ft=z(8, 1000), d_z1=z(8, 128), d_w1=z(128, 1000))

@@ -337,3 +337,35 @@ def test_classifier_train_step_phase_splits_are_identical(hip, shape):
             assert torch.equal(a, r), seq
     with pytest.raises(hip.NnueHipError):
         hip.classifier_train_step(x, True, *p, labels, phases=4)
+
+
+@pytest.mark.parametrize("shape", [(512, 1024, 128, 32, 10), (33, 256, 48, 16, 7)])
+def test_classifier_train_step_leaves_dw1_to_the_rider(hip, shape):
+    """phases bit 16: no first-layer weight product here (d_w1 untouched); d_z1 sits at the published scratch offset,
+    and d_z1^T l0 formed from it is the d_w1 of the plain call; everything else keeps its bits."""
+    b, l1, l2, l3, c = shape
+    gen = torch.Generator().manual_seed(sum(shape) + 1)
+    x = g(torch.randn(b, l1, generator=gen))
+    mk = lambda *s: torch.randn(*s, generator=gen) / (s[-1] ** 0.5)  # noqa: E731
+    p = [g(t) for t in (mk(l2, l1), mk(l2) * 0.1, mk(l3, l2), mk(l3) * 0.1, mk(c, l3), mk(c) * 0.1)]
+    labels = g(torch.randint(0, c, (b,), generator=gen))
+    nbytes = hip.classifier_train_scratch_bytes(b, l1, l2, l3, c)
+    ref = hip.classifier_train_step(x, True, *p, labels, 0.5, 0.0, phases=3,
+                                    scratch=torch.empty((nbytes,), dtype=torch.uint8, device=DEV))
+    scratch = torch.empty((nbytes,), dtype=torch.uint8, device=DEV)
+    grads = [torch.full_like(t, 7.0) for t in ref[3]]
+    got = hip.classifier_train_step(x, True, *p, labels, 0.5, 0.0, scratch=scratch, phases=17, grads=grads)
+    got = hip.classifier_train_step(x, True, *p, labels, 0.5, 0.0, scratch=scratch, phases=18, out=got[0], loss_out=got[1],
+                                    d_x=got[2], grads=got[3])
+    assert torch.equal(got[2], ref[2]) and torch.equal(got[1][1], ref[1][1]) and torch.equal(got[0][2], ref[0][2])
+    assert torch.equal(got[3][0], torch.full_like(ref[3][0], 7.0))
+    for a, r in zip(got[3][1:], ref[3][1:]):
+        assert torch.equal(a, r)
+    off = hip.classifier_train_dz1_offset(b, l1, l2, l3, c, True)
+    assert off >= 0 and off % 16 == 0 and off + b * l2 * 4 <= nbytes
+    d_z1 = scratch[off:off + b * l2 * 4].view(torch.float32).view(b, l2).double().cpu()
+    x64 = x.double().cpu()
+    l0 = torch.cat([x64[:, :l1 // 2] * x64[:, l1 // 2:], x64[:, :l1 // 2]], dim=1)
+    assert_close_grad(ref[3][0].cpu(), d_z1.t() @ l0, "d_w1 from the published d_z1", rtol=2e-5)
+    with pytest.raises(hip.NnueHipError):
+        hip.classifier_train_step(x, True, *p, labels, phases=23)  # 4 and 16 exclude each other
