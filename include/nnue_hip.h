@@ -273,7 +273,8 @@ int nnue_classifier_backward(const float* x, int pairwise,
  * FeatureTransformer forward forms them in its epilogue); phase 1 then launches no layer-1 product of its own.
  * Adding 16 (not together with 4) says d_w1 is produced by nnue_ftm_backward's rider from the d_z1 this call leaves
  * in scratch at byte offset nnue_classifier_train_dz1_offset (-1 for non-positive sizes): no first-layer weight
- * product and no slab sum are launched here, d_w1 is not written.
+ * product and no slab sum are launched here, d_w1 is not written; with both phases in the one call (19, 27) the
+ * small weight/bias gradients and the mean loss share the d_x launch.
  * scratch >= nnue_classifier_train_scratch(B, L1, L2, L3, C) bytes. */
 int64_t nnue_classifier_train_scratch(int B, int L1, int L2, int L3, int C);
 int64_t nnue_classifier_train_dz1_offset(int B, int L1, int L2, int L3, int C, int pairwise);

@@ -433,18 +433,34 @@ __global__ __launch_bounds__(128) void tail_backward_kernel(const float* __restr
 //   d_w3 [C, L3] | d_w2 [L3, L2]   four adjacent columns per wave (one float4 load feeds four sums; needs
 //                                   L3 % 4 == 0 resp. L2 % 4 == 0, else one column per wave)
 //   d_b3 [C] | d_b2 [L3] | d_b1 [L2]  one output per wave
-__global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restrict__ d_logits,
-                                                          const float* __restrict__ d_z2, const float* __restrict__ d_z1,
-                                                          const float* __restrict__ h1, const float* __restrict__ h2,
-                                                          int B, int L2, int L3, int C, float* __restrict__ d_w3,
-                                                          float* __restrict__ d_b3, float* __restrict__ d_w2,
-                                                          float* __restrict__ d_b2, float* __restrict__ d_b1,
-                                                          const float* __restrict__ sample_loss,
-                                                          float* __restrict__ loss_out, int wgrad_blocks,
-                                                          const float* __restrict__ slabs, int n_slabs,
-                                                          long long slab_count, float* __restrict__ d_w1) {
-  if ((int)blockIdx.x >= wgrad_blocks) {  // piggy-backed pass: fixed-order sum of the d_w1 split-K slabs
-    const long long i = ((long long)(blockIdx.x - wgrad_blocks) * 256 + threadIdx.x) * 4;
+struct SmallWgrad {
+  const float *d_logits, *d_z2, *d_z1, *h1, *h2;
+  int B, L2, L3, C;
+  float *d_w3, *d_b3, *d_w2, *d_b2, *d_b1;
+  const float* sample_loss;
+  float* loss_out;
+  int wgrad_blocks;
+  const float* slabs;
+  int n_slabs;
+  long long slab_count;
+  float* d_w1;
+};
+
+__device__ __forceinline__ void small_wgrad_body(const SmallWgrad& a, int blk) {
+  const float* __restrict__ d_logits = a.d_logits;
+  const float* __restrict__ d_z2 = a.d_z2;
+  const float* __restrict__ d_z1 = a.d_z1;
+  const float* __restrict__ h1 = a.h1;
+  const float* __restrict__ h2 = a.h2;
+  const float* __restrict__ sample_loss = a.sample_loss;
+  const float* __restrict__ slabs = a.slabs;
+  float* __restrict__ d_w3 = a.d_w3; float* __restrict__ d_b3 = a.d_b3; float* __restrict__ d_w2 = a.d_w2;
+  float* __restrict__ d_b2 = a.d_b2; float* __restrict__ d_b1 = a.d_b1; float* __restrict__ loss_out = a.loss_out;
+  float* __restrict__ d_w1 = a.d_w1;
+  const int B = a.B, L2 = a.L2, L3 = a.L3, C = a.C, wgrad_blocks = a.wgrad_blocks, n_slabs = a.n_slabs;
+  const long long slab_count = a.slab_count;
+  if (blk >= wgrad_blocks) {  // piggy-backed pass: fixed-order sum of the d_w1 split-K slabs
+    const long long i = ((long long)(blk - wgrad_blocks) * 256 + threadIdx.x) * 4;
     if (i >= slab_count) return;
     float4 acc = *reinterpret_cast<const float4*>(slabs + i);
     for (int s2 = 1; s2 < n_slabs; ++s2) {
@@ -454,7 +470,7 @@ __global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restric
     *reinterpret_cast<float4*>(d_w1 + i) = acc;
     return;
   }
-  long long o = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  long long o = (long long)blk * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int v3 = (L3 % 4 == 0) ? 4 : 1, v2 = (L2 % 4 == 0) ? 4 : 1;
   const long long n_w3 = (long long)C * (L3 / v3), n_w2 = (long long)L3 * (L2 / v2);
@@ -506,6 +522,8 @@ __global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restric
   acc = wave_sum(acc);
   if (lane == 0) *dst = acc;
 }
+
+__global__ __launch_bounds__(256) void small_wgrad_kernel(SmallWgrad a) { small_wgrad_body(a, (int)blockIdx.x); }
 
 // ------------------------------------------------------------------ fused narrow layers + loss (training)
 // Per sample, out of LDS: h1 = act(sum of split-K slabs + b1), h2, logits, softmax cross-entropy, d_logits,
@@ -750,9 +768,9 @@ extern "C" int nnue_classifier_backward(const float* x, int pairwise, const floa
                      clip, L2, L3, C, d_z1, d_z2);
   {
     const long long outs = (long long)C * (L3 % 4 == 0 ? L3 / 4 : L3) + (long long)L3 * (L2 % 4 == 0 ? L2 / 4 : L2) + C + L3 + L2;
-    hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, s, d_logits, d_z2, d_z1, h1, h2, B,
-                       L2, L3, C, d_w3, d_b3, d_w2, d_b2, d_b1, (const float*)nullptr, (float*)nullptr,
-                       (int)((outs + 3) / 4), (const float*)nullptr, 0, 0ll, (float*)nullptr);
+    const SmallWgrad a{d_logits, d_z2, d_z1, h1, h2, B, L2, L3, C, d_w3, d_b3, d_w2, d_b2, d_b1, nullptr, nullptr, (int)((outs + 3) / 4),
+                       nullptr, 0, 0ll, nullptr};
+    hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, s, a);
   }
   if (p.bww_mfma) {
     const long long waves = (long long)(L2 / 32) * (L1 / 64) * p.bww_ksplit;
@@ -779,6 +797,15 @@ extern "C" int nnue_classifier_backward(const float* x, int pairwise, const floa
     }
   }
   return nnue_launch_status("nnue_classifier_backward");
+}
+
+// d_x and the small weight/bias gradients + mean loss in one launch: both only read what the per-sample tail kernel
+// left (d_z1 resp. d_logits, d_z2, h1, h2), so the two launch-sized jobs share the chip (x blocks first).
+__global__ __launch_bounds__(256) void l1_backward_x_small_wgrad(const float* __restrict__ x, int pairwise, const float* __restrict__ w1,
+                                                                 const float* __restrict__ d_z1, int B, int L1, int L2,
+                                                                 float* __restrict__ d_x, int x_blocks, SmallWgrad a) {
+  if ((int)blockIdx.x < x_blocks) l1_backward_x_body(x, pairwise, w1, d_z1, B, L1, L2, d_x, blockIdx.x);
+  else small_wgrad_body(a, (int)blockIdx.x - x_blocks);
 }
 
 // ---------------------------------------------------------------- fused training step of the classifier block
@@ -851,6 +878,15 @@ extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const fl
   // same bit then only sums its slabs
   const bool early_bww = (phases & 4) && p.bwx_mfma && p.bww_mfma && d_x != nullptr;
   const int tail_slabs = ext_slabs ? L1 / 64 : p.fwd_ksplit;
+  // one launch: the small weight/bias gradients, the mean loss and (piggy-backed) the d_w1 slab sum
+  const long long outs = (long long)C * (L3 % 4 == 0 ? L3 / 4 : L3) + (long long)L3 * (L2 % 4 == 0 ? L2 / 4 : L2) + C + L3 + L2 + 1;
+  const int wgrad_blocks = (int)((outs + 3) / 4);
+  const long long count = (long long)L2 * L1;
+  const int slab_blocks = slab_pass && !ext_dw1 ? (int)((count / 4 + 255) / 256) : 0;
+  const SmallWgrad sw{d_logits, d_z2, d_z1, h1, h2, B, L2, L3, C, d_w3, d_b3, d_w2, d_b2, d_b1, sample_loss, loss, wgrad_blocks,
+                      slabs, slab_pass && !ext_dw1 ? p.bww_ksplit : 0, count, d_w1};
+  // both phases in one call with d_w1 left to nnue_ftm_backward: the small gradients ride in the d_x launch
+  const bool wgrad_rides = (phases & 3) == 3 && ext_dw1 && p.bwx_mfma && d_x != nullptr;
   if (phases & 1) {
     if (ext_slabs) {
       // part[L1/64][B][L2] was written by nnue_ftm_forward_l1 (the FeatureTransformer forward's epilogue)
@@ -873,6 +909,11 @@ extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const fl
         const int w_blocks = (int)((ww + 3) / 4);
         hipLaunchKernelGGL(l1_backward_xw_mfma, dim3((unsigned)(w_blocks + (xw + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1, L2,
                            d_x, w_blocks, p.bww_ksplit, p.bww_klen, slab_pass ? slabs : d_w1);
+      } else if (wgrad_rides) {
+        const long long waves = (long long)((B + 15) / 16) * (L1 / 32);
+        const int x_blocks = (int)((waves + 3) / 4);
+        hipLaunchKernelGGL(l1_backward_x_small_wgrad, dim3((unsigned)(x_blocks + wgrad_blocks)), dim3(256), 0, s, x, pairwise, w1,
+                           (const float*)d_z1, B, L1, L2, d_x, x_blocks, sw);
       } else if (p.bwx_mfma) {
         const long long waves = (long long)((B + 15) / 16) * (L1 / 32);
         hipLaunchKernelGGL(l1_backward_x_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1, L2, d_x);
@@ -882,6 +923,7 @@ extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const fl
       }
     }
   }
+  if (wgrad_rides) return nnue_launch_status("nnue_classifier_train_step");
   if (phases & 2) {  // needs phase 1's h1, h2, d_logits, d_z1, d_z2 (scratch) -- nothing downstream depends on it
     if (early_bww || ext_dw1) {
       // the first-layer product already ran beside d_x (phases bit 4), or rides in nnue_ftm_backward's launch (bit 16)
@@ -892,14 +934,7 @@ extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const fl
     } else {
       hipLaunchKernelGGL(l1_backward_w_simple, dim3(L2, (L1 + 255) / 256), dim3(256), 0, s, x, pairwise, d_z1, B, L1, L2, d_w1);
     }
-    // one launch: the small weight/bias gradients, the mean loss and (piggy-backed) the d_w1 slab sum
-    const long long outs = (long long)C * (L3 % 4 == 0 ? L3 / 4 : L3) + (long long)L3 * (L2 % 4 == 0 ? L2 / 4 : L2) + C + L3 + L2 + 1;
-    const int wgrad_blocks = (int)((outs + 3) / 4);
-    const long long count = (long long)L2 * L1;
-    const int slab_blocks = slab_pass && !ext_dw1 ? (int)((count / 4 + 255) / 256) : 0;
-    hipLaunchKernelGGL(small_wgrad_kernel, dim3(wgrad_blocks + slab_blocks), dim3(256), 0, s, d_logits, d_z2, d_z1, h1, h2, B, L2, L3, C,
-                       d_w3, d_b3, d_w2, d_b2, d_b1, (const float*)sample_loss, loss, wgrad_blocks, (const float*)slabs,
-                       slab_pass && !ext_dw1 ? p.bww_ksplit : 0, count, d_w1);
+    hipLaunchKernelGGL(small_wgrad_kernel, dim3(wgrad_blocks + slab_blocks), dim3(256), 0, s, sw);
   }
   return nnue_launch_status("nnue_classifier_train_step");
 }

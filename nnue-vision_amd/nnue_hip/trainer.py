@@ -253,7 +253,7 @@ class NnueTrainer:
                 # the forward's epilogue also forms the classifier's layer-1 slabs (start of its scratch)
                 lib.ftm_forward_l1(p["input.weight"], p["input.bias"], self.fm, p["classifier.classifier.0.weight"], self.cls_scratch,
                                    out=self.ft)
-                self._cls_step(25 if self.ride_dw1 else 13)
+                self._cls_step(27 if self.ride_dw1 else 13)  # 27: both phases, d_w1 left to the merged backward
                 return
             if self.use_mfma:
                 lib.ftm_forward(p["input.weight"], p["input.bias"], self.fm, out=self.ft)
@@ -261,7 +261,7 @@ class NnueTrainer:
                 lib.ftb_forward(p["input.weight"], p["input.bias"], self.bits, out=self.ft)
             else:
                 lib.ft_forward(p["input.weight"], p["input.bias"], self.act, out=self.ft)
-            self._cls_step(17 if self.ride_dw1 else 5)  # 5: + the first-layer weight product beside d_x
+            self._cls_step(19 if self.ride_dw1 else 5)  # 5: + the first-layer weight product beside d_x
         elif name == "ft_wgrad":
             if self.use_mfma and self.merge_backward:
                 # weight gradient, value gradient and tail rows share one launch (independent work, all read d_ft)
@@ -275,7 +275,8 @@ class NnueTrainer:
             else:
                 lib.ft_backward_weight(self.d_ft, self.act, self.F, d_weight=g["input.weight"], d_bias=g["input.bias"])
         elif name == "cls_wgrad":
-            self._cls_step(18 if self.ride_dw1 else 6)
+            if not self.ride_dw1:  # else the small gradients already rode in the d_x launch of "forward"
+                self._cls_step(6)
         elif name == "tail":
             if self.use_mfma and self.merge_backward:
                 pass  # d_conv_out came out of the merged launch in "ft_wgrad"

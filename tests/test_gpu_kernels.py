@@ -361,6 +361,11 @@ def test_classifier_train_step_leaves_dw1_to_the_rider(hip, shape):
     assert torch.equal(got[3][0], torch.full_like(ref[3][0], 7.0))
     for a, r in zip(got[3][1:], ref[3][1:]):
         assert torch.equal(a, r)
+    once = hip.classifier_train_step(x, True, *p, labels, 0.5, 0.0, phases=19, grads=[torch.full_like(t, 7.0) for t in ref[3]],
+                                     scratch=torch.empty((nbytes,), dtype=torch.uint8, device=DEV))
+    assert torch.equal(once[2], ref[2]) and torch.equal(once[1][1], ref[1][1]) and torch.equal(once[0][2], ref[0][2])
+    for a, r in zip(once[3], got[3]):
+        assert torch.equal(a, r)
     off = hip.classifier_train_dz1_offset(b, l1, l2, l3, c, True)
     assert off >= 0 and off % 16 == 0 and off + b * l2 * 4 <= nbytes
     d_z1 = scratch[off:off + b * l2 * 4].view(torch.float32).view(b, l2).double().cpu()
