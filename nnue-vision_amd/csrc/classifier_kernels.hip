@@ -548,7 +548,7 @@ __device__ __forceinline__ float block_reduce_nt(float v, bool is_max, float* re
 
 // NT threads per sample: 128 for the usual class counts, 512 when C is large (1000 classes at 224x224: the logits,
 // the softmax and the d_z2 sum are then 4x wider per pass).
-template <int NT>
+template <int NT, bool VEC>
 __global__ __launch_bounds__(NT) void tail_train_kernel(const float* __restrict__ part, int ksplit,
                                                         const float* __restrict__ b1, const float* __restrict__ w2,
                                                         const float* __restrict__ b2, const float* __restrict__ w3,
@@ -568,25 +568,65 @@ __global__ __launch_bounds__(NT) void tail_train_kernel(const float* __restrict_
   float* red = dz2s + L3;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int og = tid >> 2, part4 = tid & 3;
+  // VEC (L2 % 4 == 0, L3 % 4 == 0, 16-byte aligned w2 / w3): a thread's share of a weight row is float4 runs, and the
+  // first pass's runs are requested before the slab sum so that their latency hides behind it
+  constexpr int kPre2 = 8, kPre3 = 2;
+  float4 w2v[kPre2], w3v[kPre3];
+  if constexpr (VEC) {
+#pragma unroll
+    for (int i = 0; i < kPre2; ++i) {
+      const int k = 4 * (part4 + 4 * i);
+      w2v[i] = (og < L3 && k < L2) ? *reinterpret_cast<const float4*>(w2 + (size_t)og * L2 + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < kPre3; ++i) {
+      const int k = 4 * (part4 + 4 * i);
+      w3v[i] = (og < C && k < L3) ? *reinterpret_cast<const float4*>(w3 + (size_t)og * L3 + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const float b2v = (VEC && og < L3) ? b2[og] : 0.0f, b3v = (VEC && og < C) ? b3[og] : 0.0f;
+  const int64_t y = labels[b];
   for (int j = tid; j < L2; j += NT) {
     float z = b1[j];
-    for (int s = 0; s < ksplit; ++s) z += part[((size_t)s * B + b) * L2 + j];
+    int s = 0;
+    for (; s + 8 <= ksplit; s += 8) {  // eight loads in flight, summed in slab order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[((size_t)(s + u) * B + b) * L2 + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) z += v[u];
+    }
+    for (; s < ksplit; ++s) z += part[((size_t)s * B + b) * L2 + j];
     const float h = act_fn(z, clip);
     h1s[j] = h;
     h1[(size_t)b * L2 + j] = h;
   }
   __syncthreads();
+  auto dot4 = [](const float4& w, const float4& h, float z) { return fmaf(w.w, h.w, fmaf(w.z, h.z, fmaf(w.y, h.y, fmaf(w.x, h.x, z)))); };
   for (int j0 = 0; j0 < L3; j0 += NT / 4) {
     const int j = j0 + og;
     float z = 0.f;
     if (j < L3) {
       const float* __restrict__ wr = w2 + (size_t)j * L2;
-      for (int k = part4; k < L2; k += 4) z = fmaf(wr[k], h1s[k], z);
+      if constexpr (VEC) {
+        int k = 4 * part4;
+        if (j0 == 0) {
+#pragma unroll
+          for (int i = 0; i < kPre2; ++i) {
+            const int kk = 4 * (part4 + 4 * i);
+            if (kk < L2) z = dot4(w2v[i], *reinterpret_cast<const float4*>(h1s + kk), z);
+          }
+          k += 16 * kPre2;
+        }
+        for (; k < L2; k += 16) z = dot4(*reinterpret_cast<const float4*>(wr + k), *reinterpret_cast<const float4*>(h1s + k), z);
+      } else {
+        for (int k = part4; k < L2; k += 4) z = fmaf(wr[k], h1s[k], z);
+      }
     }
     z += __shfl_xor(z, 1);
     z += __shfl_xor(z, 2);
     if (j < L3 && part4 == 0) {
-      const float h = act_fn(z + b2[j], clip);
+      const float h = act_fn(z + ((VEC && j0 == 0) ? b2v : b2[j]), clip);
       h2s[j] = h;
       h2[(size_t)b * L3 + j] = h;
     }
@@ -597,25 +637,47 @@ __global__ __launch_bounds__(NT) void tail_train_kernel(const float* __restrict_
     float z = 0.f;
     if (c < C) {
       const float* __restrict__ wr = w3 + (size_t)c * L3;
-      for (int k = part4; k < L3; k += 4) z = fmaf(wr[k], h2s[k], z);
+      if constexpr (VEC) {
+        int k = 4 * part4;
+        if (c0 == 0) {
+#pragma unroll
+          for (int i = 0; i < kPre3; ++i) {
+            const int kk = 4 * (part4 + 4 * i);
+            if (kk < L3) z = dot4(w3v[i], *reinterpret_cast<const float4*>(h2s + kk), z);
+          }
+          k += 16 * kPre3;
+        }
+        for (; k < L3; k += 16) z = dot4(*reinterpret_cast<const float4*>(wr + k), *reinterpret_cast<const float4*>(h2s + k), z);
+      } else {
+        for (int k = part4; k < L3; k += 4) z = fmaf(wr[k], h2s[k], z);
+      }
     }
     z += __shfl_xor(z, 1);
     z += __shfl_xor(z, 2);
     if (c < C && part4 == 0) {
-      z += b3[c];
+      z += (VEC && c0 == 0) ? b3v : b3[c];
       lgs[c] = z;
       logits[(size_t)b * C + c] = z;
     }
   }
   __syncthreads();
   // softmax cross-entropy of this sample and its gradient
-  float mx = -INFINITY;
-  for (int c = tid; c < C; c += NT) mx = fmaxf(mx, lgs[c]);
-  mx = block_reduce_nt<NT>(mx, true, red);
-  float se = 0.f;
-  for (int c = tid; c < C; c += NT) se += expf(lgs[c] - mx);
-  se = block_reduce_nt<NT>(se, false, red);
-  const int64_t y = labels[b];
+  float mx = -INFINITY, se = 0.f;
+  if (C <= 64) {  // every wave forms the same two reductions by itself: no block barriers
+    const int lane = tid & 63;
+    const float v = lane < C ? lgs[lane] : -INFINITY;
+    mx = v;
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) mx = fmaxf(mx, __shfl_xor(mx, sh));
+    se = lane < C ? expf(v - mx) : 0.0f;
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) se += __shfl_xor(se, sh);
+  } else {
+    for (int c = tid; c < C; c += NT) mx = fmaxf(mx, lgs[c]);
+    mx = block_reduce_nt<NT>(mx, true, red);
+    for (int c = tid; c < C; c += NT) se += expf(lgs[c] - mx);
+    se = block_reduce_nt<NT>(se, false, red);
+  }
   const bool ok = y >= 0 && y < C;
   if (tid == 0) sample_loss[b] = ok ? (mx + logf(se)) - lgs[y] : 0.0f;
   const float inv = 1.0f / se;
@@ -660,9 +722,18 @@ __global__ __launch_bounds__(NT) void tail_train_kernel(const float* __restrict_
   }
   for (int k = tid; k < L2; k += NT) {
     float s = 0.f;
-    for (int j = 0; j < L3; ++j) s = fmaf(dz2s[j], w2[(size_t)j * L2 + k], s);
+    int j = 0;
+    for (; j + 16 <= L3; j += 16) {  // sixteen rows in flight, summed in row order
+      float w[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) w[u] = w2[(size_t)(j + u) * L2 + k];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s = fmaf(dz2s[j + u], w[u], s);
+    }
+    for (; j < L3; ++j) s = fmaf(dz2s[j], w2[(size_t)j * L2 + k], s);
     d_z1[(size_t)b * L2 + k] = s * gate_fn(h1s[k], clip);
   }
+  __syncthreads();
 }
 
 // ------------------------------------------------------------------ shape policy (shared by scratch + launch)
@@ -897,12 +968,13 @@ extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const fl
       const long long waves = (long long)B * L2;
       hipLaunchKernelGGL(l1_forward_simple, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, B, L1, L2, part);
     }
-    if (C > 256)
-      hipLaunchKernelGGL(tail_train_kernel<512>, dim3(B), dim3(512), (size_t)tail_lds, s, part, tail_slabs, b1, w2, b2, w3, b3, clip, labels,
-                         grad_scale / (float)B, B, L2, L3, C, h1, h2, logits, sample_loss, d_logits, d_z1, d_z2);
-    else
-      hipLaunchKernelGGL(tail_train_kernel<128>, dim3(B), dim3(128), (size_t)tail_lds, s, part, tail_slabs, b1, w2, b2, w3, b3, clip, labels,
-                         grad_scale / (float)B, B, L2, L3, C, h1, h2, logits, sample_loss, d_logits, d_z1, d_z2);
+    const bool vec = L2 % 4 == 0 && L3 % 4 == 0 && nnue_aligned16(w2) && nnue_aligned16(w3);
+#define NNUE_TAIL(NT, V)                                                                                                                  \
+  hipLaunchKernelGGL((tail_train_kernel<NT, V>), dim3(B), dim3(NT), (size_t)tail_lds, s, part, tail_slabs, b1, w2, b2, w3, b3, clip, labels, \
+                     grad_scale / (float)B, B, L2, L3, C, h1, h2, logits, sample_loss, d_logits, d_z1, d_z2)
+    if (C > 256) { if (vec) NNUE_TAIL(512, true); else NNUE_TAIL(512, false); }
+    else { if (vec) NNUE_TAIL(128, true); else NNUE_TAIL(128, false); }
+#undef NNUE_TAIL
     if (d_x) {
       if (p.bwx_mfma && early_bww) {
         const long long xw = (long long)((B + 15) / 16) * (L1 / 32), ww = (long long)(L2 / 32) * (L1 / 64) * p.bww_ksplit;
@@ -938,3 +1010,4 @@ extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const fl
   }
   return nnue_launch_status("nnue_classifier_train_step");
 }
+
