@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void ste_conv_backward_stage1(const float* __r
   }
   __syncthreads();
   if (threadIdx.x < 28)
-    partial[((size_t)chunk * fps + c) * 28 + threadIdx.x] =
+    partial[((size_t)c * 28 + threadIdx.x) * gridDim.y + chunk] =
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
@@ -358,33 +358,45 @@ __global__ __launch_bounds__(256) void ste_conv_backward_mfma(const float* __res
 #pragma unroll
       for (int e = 0; e < 4; ++e) red[wave][(i * 2 + t) * 4 + e][lane] = acc[i][t][e];
   __syncthreads();
-  float* __restrict__ out = partial + (size_t)blockIdx.x * fps * 28;
+  // partial[(channel * 28 + term) * blocks + block]: stage 2 reads each output's partials as one contiguous run
+  float* __restrict__ out = partial + blockIdx.x;
+  const size_t os = gridDim.x;
   for (int o = threadIdx.x; o < MT * 16 * 32; o += 256) {
     const int c = o >> 5, qq = o & 31;
     if (c >= fps || qq >= 27) continue;
     // accumulator register e of lane 16 * qd + rr holds D[row 4 * qd + e][col rr]
     const int i = c >> 4, row = c & 15, t = qq >> 4, rr = qq & 15;
     const int slot = (i * 2 + t) * 4 + (row & 3), ln = (row >> 2) * 16 + rr;
-    out[c * 28 + qq] = (red[0][slot][ln] + red[1][slot][ln]) + (red[2][slot][ln] + red[3][slot][ln]);
+    out[(size_t)(c * 28 + qq) * os] = (red[0][slot][ln] + red[1][slot][ln]) + (red[2][slot][ln] + red[3][slot][ln]);
   }
 #pragma unroll
   for (int j = 0; j < MT * 4; ++j) {
     float v = tacc[j];
 #pragma unroll
     for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft);
-    if (lane == 0 && wave + 4 * j < fps) out[(wave + 4 * j) * 28 + 27] = v;
+    if (lane == 0 && wave + 4 * j < fps) out[(size_t)((wave + 4 * j) * 28 + 27) * os] = v;
   }
 }
 
-// one wave per (channel, term): lanes stride over the chunk partials, fixed-shape tree sum
+// one wave per (channel, term): lanes stride over the output's contiguous run of partials (eight loads in flight),
+// fixed-shape tree sum
 __global__ __launch_bounds__(256) void ste_conv_backward_stage2(const float* __restrict__ partial, int chunks, int fps,
                                                                 float* __restrict__ d_thr, float* __restrict__ d_weight) {
   const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (o >= fps * 28) return;
   const int c = o / 28, q = o - c * 28;
+  const float* __restrict__ run = partial + (size_t)o * chunks;
   float acc = 0.0f;
-  for (int k = lane; k < chunks; k += 64) acc += partial[((size_t)k * fps + c) * 28 + q];
+  int k = lane;
+  for (; k + 7 * 64 < chunks; k += 8 * 64) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = run[k + 64 * u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; k < chunks; k += 64) acc += run[k];
 #pragma unroll
   for (int sft = 32; sft >= 1; sft >>= 1) acc += __shfl_xor(acc, sft);
   if (lane != 0) return;
@@ -407,6 +419,7 @@ int ste_chunks(int B, int fps) {
 // CU once there is that much work, never more than kSteMaxBlocks
 int64_t ste_mfma_blocks(int64_t positions) {
   const int64_t tiles = (positions + kStePos - 1) / kStePos;
+  if (tiles <= kSteMaxBlocks) return tiles > 0 ? tiles : 1;  // one tile per workgroup: a single load latency, all resident
   int64_t blocks = (tiles + 1) / 2;
   if (blocks < 256) blocks = tiles < 256 ? tiles : 256;
   if (blocks > kSteMaxBlocks) blocks = kSteMaxBlocks;

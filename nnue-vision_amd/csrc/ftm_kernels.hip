@@ -153,31 +153,65 @@ constexpr int gemm_lds_floats() {
 // [BM x 64] x [64 x L2] product on the MFMA with the w1 fragments read straight from memory (L2-resident, 32 KB per
 // workgroup).  smem: BM x 68 floats for the ft tile + BM x 68 for the l0 tile.
 constexpr int kL1Ld = 68;
+// Everything the epilogue reads from memory is requested before the K loop (FusedL1Pre), so that none of its
+// latencies is left at the end of the tile: sink / bias / last table row, and the w1 fragments of this wave's first
+// two 16-unit column tiles.
+constexpr int kL1PreTiles = 2;
 template <int BM>
-__device__ __forceinline__ void fused_l1_epilogue(const FwdL1Epi& e, float* __restrict__ smem, const f32x4 (&acc)[BM / 32][2], int m_base,
-                                                  int tile_n, int m0, int n0, int r, int q, int wave, int tid) {
-  float* __restrict__ T = smem;
-  float* __restrict__ L0 = smem + BM * kL1Ld;
-  constexpr int TM = BM / 32;
-  float sk[TM][4];
+struct FusedL1Pre {
+  float sk[BM / 32][4];
+  float bv[2], wl[2];
+  float4 bq[kL1PreTiles][4];
+};
+
+template <int BM>
+__device__ __forceinline__ void fused_l1_prefetch(const FwdL1Epi& e, FusedL1Pre<BM>& p, int m_base, int tile_n, int m0, int n0, int r,
+                                                  int q, int wave) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < BM / 32; ++i)
 #pragma unroll
     for (int ee = 0; ee < 4; ++ee) {
       const int m = m_base + m0 + 16 * i + 4 * q + ee;
-      sk[i][ee] = m < e.B ? e.sink[m] : 0.0f;
+      p.sk[i][ee] = m < e.B ? e.sink[m] : 0.0f;
     }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int colg = e.col(tile_n * 64 + n0 + 16 * t + r);
+    p.bv[t] = e.bias[colg];
+    p.wl[t] = e.w_last[colg];
+  }
+#pragma unroll
+  for (int s = 0; s < kL1PreTiles; ++s) {
+    const int j = (wave + 4 * s) * 16 + r;
+    const bool jok = j < e.L2;
+    const float* __restrict__ wrow = e.w1 + (size_t)(jok ? j : 0) * e.L1;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const int k = kb * 16 + 4 * q;  // tile-local l0 column; 4 consecutive columns stay inside one 32-column run
+      const int colg = k < 32 ? tile_n * 32 + k : e.half + tile_n * 32 + (k - 32);
+      p.bq[s][kb] = jok ? *reinterpret_cast<const float4*>(wrow + colg) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+
+template <int BM>
+__device__ __forceinline__ void fused_l1_epilogue(const FwdL1Epi& e, const FusedL1Pre<BM>& p, float* __restrict__ smem,
+                                                  const f32x4 (&acc)[BM / 32][2], int m_base, int tile_n, int m0, int n0, int r, int q,
+                                                  int wave, int tid) {
+  float* __restrict__ T = smem;
+  float* __restrict__ L0 = smem + BM * kL1Ld;
+  constexpr int TM = BM / 32;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int n_loc = n0 + 16 * t + r;
     const int colg = e.col(tile_n * 64 + n_loc);
-    const float bv = e.bias[colg], wl = e.w_last[colg];
+    const float bv = p.bv[t], wl = p.wl[t];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int ee = 0; ee < 4; ++ee) {
         const int m_loc = m0 + 16 * i + 4 * q + ee, m = m_base + m_loc;
-        const float v = acc[i][t][ee] + fmaf(sk[i][ee], wl, bv);  // same arithmetic as FwdEpi
+        const float v = acc[i][t][ee] + fmaf(p.sk[i][ee], wl, bv);  // same arithmetic as FwdEpi
         if (m < e.B) e.out[(size_t)m * e.L1 + colg] = v;
         T[m_loc * kL1Ld + n_loc] = m < e.B ? v : 0.0f;
       }
@@ -190,17 +224,8 @@ __device__ __forceinline__ void fused_l1_epilogue(const FwdL1Epi& e, float* __re
   }
   __syncthreads();
   const int n_tiles = (e.L2 + 15) / 16;
-  for (int nt = wave; nt < n_tiles; nt += 4) {
+  auto column_tile = [&](int nt, const float4 (&bq)[4]) {
     const int j = nt * 16 + r;
-    const bool jok = j < e.L2;
-    const float* __restrict__ wrow = e.w1 + (size_t)(jok ? j : 0) * e.L1;
-    float4 bq[4];
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const int k = kb * 16 + 4 * q;  // tile-local l0 column; 4 consecutive columns stay inside one 32-column run
-      const int colg = k < 32 ? tile_n * 32 + k : e.half + tile_n * 32 + (k - 32);
-      bq[kb] = jok ? *reinterpret_cast<const float4*>(wrow + colg) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
     f32x4 z[BM / 16];
 #pragma unroll
     for (int mt = 0; mt < BM / 16; ++mt) z[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -215,7 +240,7 @@ __device__ __forceinline__ void fused_l1_epilogue(const FwdL1Epi& e, float* __re
         z[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq[kb].w, z[mt], 0, 0, 0);
       }
     }
-    if (jok) {
+    if (j < e.L2) {
 #pragma unroll
       for (int mt = 0; mt < BM / 16; ++mt)
 #pragma unroll
@@ -224,6 +249,22 @@ __device__ __forceinline__ void fused_l1_epilogue(const FwdL1Epi& e, float* __re
           if (m < e.B) e.part[((size_t)tile_n * e.B + m) * e.L2 + j] = z[mt][ee];
         }
     }
+  };
+#pragma unroll
+  for (int s = 0; s < kL1PreTiles; ++s)
+    if (wave + 4 * s < n_tiles) column_tile(wave + 4 * s, p.bq[s]);
+  for (int nt = wave + 4 * kL1PreTiles; nt < n_tiles; nt += 4) {
+    const int j = nt * 16 + r;
+    const bool jok = j < e.L2;
+    const float* __restrict__ wrow = e.w1 + (size_t)(jok ? j : 0) * e.L1;
+    float4 bq[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const int k = kb * 16 + 4 * q;
+      const int colg = k < 32 ? tile_n * 32 + k : e.half + tile_n * 32 + (k - 32);
+      bq[kb] = jok ? *reinterpret_cast<const float4*>(wrow + colg) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    column_tile(nt, bq);
   }
 }
 
@@ -303,6 +344,8 @@ __device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& m
 #pragma unroll
     for (int t = 0; t < TN; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  FusedL1Pre<Epi::kFusedL1 ? BM : 32> l1pre;
+  if constexpr (Epi::kFusedL1) fused_l1_prefetch<BM>(epi, l1pre, m_base, tile_n, m0, n0, r, q, wave);
   fetch(k_lo);
   for (int k0 = k_lo; k0 < k_hi; k0 += BK) {
 #pragma unroll
@@ -349,7 +392,7 @@ __device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& m
     __syncthreads();
   }
   if constexpr (Epi::kFusedL1) {
-    fused_l1_epilogue<BM>(epi, smem, acc, m_base, tile_n, m0, n0, r, q, wave, tid);
+    fused_l1_epilogue<BM>(epi, l1pre, smem, acc, m_base, tile_n, m0, n0, r, q, wave, tid);
     return;
   } else {
   // accumulator register e of lane 16 q + r holds C[row 4 q + e][col r]; every epilogue operand is loaded before
@@ -842,3 +885,4 @@ extern "C" int nnue_ftm_forward_l1(const uint8_t* bits, const float* sink, const
   else hipLaunchKernelGGL((ftm_forward_l1_kernel<64, 64>), grid, dim3(256), 0, st, ma, mb, epi, B, L1, direct, s.tiles_n);
   return nnue_launch_status("nnue_ftm_forward_l1");
 }
+
