@@ -214,7 +214,7 @@ def main():
         kernels = data.get("workloads", {}).get(args.workload) or (data.get("kernels") if args.workload == "c2" else None)
         if not kernels:
             return None
-        want = {"nnue_ftm_forward": ("ftm_gemm_kernel", "FwdEpi"), "nnue_ftm_forward_l1": ("ftm_gemm_kernel", "FwdEpi"), "nnue_ftm_backward": ("ftm_backward_kernel", ""), "nnue_ftm_backward_weight": ("ftm_gemm_kernel", "BwwEpi"),
+        want = {"nnue_ftm_forward": ("ftm_gemm_kernel", "FwdEpi"), "nnue_ftm_forward_l1": ("ftm_forward_l1_kernel", ""), "nnue_ftm_backward": ("ftm_backward_kernel", ""), "nnue_ftm_backward_weight": ("ftm_gemm_kernel", "BwwEpi"),
                 "nnue_ftm_backward_values": ("ftm_gemm_kernel", "ValEpi"),
                 "nnue_ftb_forward": ("ftb_gather_kernel", ", 0,"), "nnue_ftb_backward_weight": ("ftb_gather_kernel", ", 1,"),
                 "nnue_ftb_backward_values": ("ftb_values_kernel", ""), "nnue_ft_forward": ("ft_forward_wide", ""),
@@ -239,6 +239,8 @@ def main():
         flops = {f"{ftp}_forward": 2.0 * B * direct * cfg["l1"], f"{ftp}_backward_weight": 2.0 * B * direct * cfg["l1"],
                  f"{ftp}_backward_values": 2.0 * B * trainer.P * cfg["l1"]}
         flops[f"{ftp}_backward"] = flops[f"{ftp}_backward_weight"] + flops[f"{ftp}_backward_values"]
+        if getattr(trainer, "ride_dw1", False):  # + the classifier's first-layer weight gradient riding in the launch
+            flops[f"{ftp}_backward"] += 2.0 * B * cfg["l1"] * cfg["l2"]
         flops[f"{ftp}_forward_l1"] = flops[f"{ftp}_forward"] + 2.0 * B * cfg["l1"] * cfg["l2"]  # + the layer-1 product
         achieved = flops[dom] / (dur_us[dom] * 1e-6) / 1e12 if dur_us[dom] > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void ftm_backward_kernel(Mat wa, Mat wb, BwwEp
                                                            Mat va, Mat vb, ValEpi ve, int vM, int vN, int vK, int v_tiles_n, int n_v,
                                                            CwArgs c, TailRows t) {
   constexpr int kW = gemm_lds_floats<WM, WN, WK, false, false>(), kV = gemm_lds_floats<VM, VN, VK, true, true>();
-  constexpr int kC = gemm_lds_floats<32, 64, 128, false, false>();
+  constexpr int kC = gemm_lds_floats<WM, WN, WK, false, false>();  // the rider's tiles have the weight tiles' shape
   constexpr int kWV = kW > kV ? kW : kV;
   __shared__ __attribute__((aligned(16))) float smem[kWV > kC ? kWV : kC];
   const int blk = blockIdx.x;
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void ftm_backward_kernel(Mat wa, Mat wb, BwwEp
   } else if (blk < n_v + n_w) {
     gemm_tile<WM, WN, WK, false, false, BwwEpi>(smem, wa, wb, we, wM, wN, wK, wK + WK, w_tiles_n, blk - n_v, 0);
   } else if (blk < n_v + n_w + c.n_c) {
-    gemm_tile<32, 64, 128, false, false, CwEpi>(smem, c.a, c.b, c.e, c.M, c.N, c.K, c.K + 128, c.tiles_n, blk - n_v - n_w, 0);
+    gemm_tile<WM, WN, WK, false, false, CwEpi>(smem, c.a, c.b, c.e, c.M, c.N, c.K, c.K + WK, c.tiles_n, blk - n_v - n_w, 0);
   } else {
     const int i = blk - n_w - n_v - c.n_c;
     tail_rows_block(t, i % t.col_blocks, i / t.col_blocks);
@@ -844,7 +844,7 @@ extern "C" int nnue_ftm_backward(const uint8_t* bits, const float* sink, const f
     cw.b = Mat{ft, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, kIntMax};
     cw.e = CwEpi{d_w1, L1, L1 / 2};
     cw.M = L2; cw.N = L1; cw.K = B; cw.tiles_n = (L1 + 63) / 64;
-    cw.n_c = ((L2 + 31) / 32) * cw.tiles_n;
+    cw.n_c = ((L2 + swr.bm - 1) / swr.bm) * cw.tiles_n;  // tiles of the weight-gradient shape (both operands row-contiguous)
   }
   const dim3 grid((unsigned)(n_w + n_v + cw.n_c + n_t));
 #define NNUE_FTM_BWD(WM, WN, WK, VM, VN, VK)                                                                                          \
