@@ -67,15 +67,13 @@ __global__ __launch_bounds__(256) void conv_binarize_kernel(const float* __restr
   extern __shared__ float w_lds[];  // [fps][27] | thr [fps]
   __shared__ int cnt_s[4], sink_s[4];
   float* thr_lds = w_lds + fps * 27;
-  for (int i = threadIdx.x; i < fps * 27; i += blockDim.x) w_lds[i] = w[i];
-  for (int i = threadIdx.x; i < fps; i += blockDim.x) thr_lds[i] = thr[i];
-  __syncthreads();
   const int G = Gh * Gw;
   const int b = blockIdx.x;
-  int cnt = 0, snk = 0;
-  for (int hw = blockIdx.y * blockDim.x + threadIdx.x; hw < G; hw += blockDim.x * slices) {
+  // the first position's patch is requested before the weights are staged: a launch starts with cold caches, and the
+  // two first-touch latencies (weights, pixels) would otherwise run one after the other
+  float patch[27];
+  auto load_patch = [&](int hw) {
     const int h = hw / Gw, x = hw - h * Gw;
-    float patch[27];
 #pragma unroll
     for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
@@ -86,6 +84,15 @@ __global__ __launch_bounds__(256) void conv_binarize_kernel(const float* __restr
           const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
           patch[ci * 9 + kh * 3 + kw] = in ? img[(((size_t)b * 3 + ci) * H + iy) * W + ix] : 0.0f;
         }
+  };
+  const int hw0 = blockIdx.y * blockDim.x + threadIdx.x;
+  if (hw0 < G) load_patch(hw0);
+  for (int i = threadIdx.x; i < fps * 27; i += blockDim.x) w_lds[i] = w[i];
+  for (int i = threadIdx.x; i < fps; i += blockDim.x) thr_lds[i] = thr[i];
+  __syncthreads();
+  int cnt = 0, snk = 0;
+  for (int hw = hw0; hw < G; hw += blockDim.x * slices) {
+    if (hw != hw0) load_patch(hw);
     for (int c0 = 0; c0 < fps; c0 += kConvChunk) {
       float acc[kConvChunk];
 #pragma unroll
@@ -460,13 +467,7 @@ extern "C" int nnue_ftm_conv_binarize(const float* images, const float* weight, 
   int slices = (512 + B - 1) / B;
   if (slices > (int)(G / threads)) slices = (int)(G / threads);
   slices = slices < 1 ? 1 : (slices > 16 ? 16 : slices);
-  if (slices > 1) {
-    if (hipMemsetAsync(n, 0, (size_t)B * sizeof(int), s) != hipSuccess || hipMemsetAsync(sink, 0, (size_t)B * sizeof(float), s) != hipSuccess) {
-      (void)hipGetLastError();
-      nnue_set_error("nnue_ftm_conv_binarize: clearing the per-sample counters failed");
-      return NNUE_E_LAUNCH;
-    }
-  }
+  if (slices > 1) nnue_zero_counters(n, sink, B, s);  // a kernel, not a memset node (common.h)
   hipLaunchKernelGGL(conv_binarize_kernel, dim3(B, slices), dim3(threads), fps * 28 * sizeof(float), s, images, weight, thr, conv_out, bits, n,
                      sink, H, W, fps, stride, Gh, Gw, F, slices);
   return nnue_launch_status("nnue_ftm_conv_binarize");

@@ -359,8 +359,7 @@ extern "C" int nnue_ft_prepare(const int64_t* idx, const float* val, int B, int 
   NNUE_REQUIRE(B > 0 && M > 0 && F > 0, NNUE_E_ARG, "nnue_ft_prepare: B=%d M=%d F=%d must be positive", B, M, F);
   NNUE_REQUIRE(ldb >= B && ldb % 64 == 0, NNUE_E_SHAPE, "nnue_ft_prepare: ldb=%d must be a multiple of 64 and >= B=%d", ldb, B);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(coefT, 0, (size_t)F * ldb * sizeof(float), s) != hipSuccess)
-    return nnue_launch_status("nnue_ft_prepare(memset)");
+  nnue_zero_floats(coefT, (size_t)F * ldb, s);  // a kernel, not a memset node (common.h)
   hipLaunchKernelGGL(ft_prepare_kernel, dim3(B), dim3(256), 0, s, idx, val, M, F, rows, pos, coef, n, coefT, ldb);
   return nnue_launch_status("nnue_ft_prepare");
 }
@@ -419,8 +418,7 @@ extern "C" int nnue_ft_backward_values(const float* d_out, const float* weight, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int S = wide_ok(L1) ? L1 / 256 : 0;
   const bool wide = (S == 1 || S == 2 || S == 4 || S == 8);
-  if (!wide && hipMemsetAsync(dst, 0, (size_t)B * dst_ld * sizeof(float), s) != hipSuccess)
-    return nnue_launch_status("nnue_ft_backward_values(memset)");
+  if (!wide) nnue_zero_floats(dst, (size_t)B * dst_ld, s);  // a kernel, not a memset node (common.h)
   if (wide) {  // the wide kernel zero-fills its own rows
     NNUE_REQUIRE(nnue_aligned16(d_out) && nnue_aligned16(weight), NNUE_E_ARG,
                  "nnue_ft_backward_values: pointers must be 16-byte aligned");

@@ -600,13 +600,7 @@ extern "C" int nnue_binarize_bits(const float* conv_out, const float* thr, int B
   if (stages & 1) {
     int slices = (pw64 / 2) / 32;  // >= 8 tiles per wave before a sample is split
     slices = slices < 1 ? 1 : (slices > 32 ? 32 : slices);
-    if (slices > 1) {
-      if (hipMemsetAsync(n, 0, (size_t)B * sizeof(int), s) != hipSuccess || hipMemsetAsync(sink, 0, (size_t)B * sizeof(float), s) != hipSuccess) {
-        (void)hipGetLastError();
-        nnue_set_error("nnue_binarize_bits: clearing the per-sample counters failed");
-        return NNUE_E_LAUNCH;
-      }
-    }
+    if (slices > 1) nnue_zero_counters(n, sink, B, s);  // a kernel, not a memset node (common.h)
     hipLaunchKernelGGL(bits_rows_kernel, dim3(B, slices), dim3(256), 0, s, conv_out, thr, Gh * Gw, P, F, reinterpret_cast<u64*>(maskW), pw64,
                        sink, n, reinterpret_cast<unsigned short*>(tlW), tcW, ntf, slices);
   }

@@ -707,13 +707,7 @@ extern "C" int nnue_ftm_binarize(const float* conv_out, const float* thr, int B,
   hipStream_t s = static_cast<hipStream_t>(stream);
   int slices = P / 8192;
   slices = slices < 1 ? 1 : (slices > 32 ? 32 : slices);
-  if (slices > 1) {
-    if (hipMemsetAsync(n, 0, (size_t)B * sizeof(int), s) != hipSuccess || hipMemsetAsync(sink, 0, (size_t)B * sizeof(float), s) != hipSuccess) {
-      (void)hipGetLastError();
-      nnue_set_error("nnue_ftm_binarize: clearing the per-sample counters failed");
-      return NNUE_E_LAUNCH;
-    }
-  }
+  if (slices > 1) nnue_zero_counters(n, sink, B, s);  // a kernel, not a memset node (common.h)
   hipLaunchKernelGGL(ftm_binarize_kernel, dim3(B, slices), dim3(256), 0, s, conv_out, thr, P, Gh * Gw, F, slices, bits, n, sink);
   return nnue_launch_status("nnue_ftm_binarize");
 }

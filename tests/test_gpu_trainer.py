@@ -41,6 +41,15 @@ def test_trainer_follows_reference_trajectory(name, use_graph):
     assert float(model.nnue2score) == 600.0
 
 
+@pytest.mark.parametrize("path", ("bits", "list"))
+def test_gather_paths_follow_the_trajectory_when_replayed(monkeypatch, path):
+    """The gather kernel families under a replayed hipGraph (NNUE_FT_PATH): regression for zero fills that were
+    memset nodes -- a memset captured ahead of a kernel scattering into the same buffer was not ordered before it."""
+    monkeypatch.setenv("NNUE_FT_PATH", path)
+    test_trainer_follows_reference_trajectory("c1arch", True)
+    test_trainer_follows_reference_trajectory("tiny96", True)
+
+
 def test_trainer_gradients_equal_autograd_path():
     torch.manual_seed(0)
     cfg = dict(grid=10, fps=8, l1=256, l2=32, l3=16, classes=10, input_size=32)
