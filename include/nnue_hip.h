@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 15
+#define NNUE_HIP_ABI_VERSION 16
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -84,12 +84,17 @@ int nnue_act_to_padded(const int32_t* pos, const float* coef, const int32_t* n, 
  * (nnue.py:28-54; autograd of the conv at nnue.py:640).
  *   d_thr[c]            = -sum_{b,h,w} d_conv_out * k*s*(1-s),  s = sigmoid(k*(x - thr[c])), k = 10
  *   d_weight[c,ci,kh,kw] = sum_{b,h,w} d_conv_out[b,c,h,w] * images[b,ci,h*stride+kh-1,w*stride+kw-1]
- * Deterministic two-stage sum; scratch >= nnue_ste_conv_backward_scratch(...) bytes. */
+ * Deterministic two-stage sum; scratch >= nnue_ste_conv_backward_scratch(...) bytes.
+ * stages: 3 = both; 1 = stage 1 only: the per-workgroup partials stay at the start of scratch as
+ * partial[(c*28+q)*chunks + k], k < nnue_ste_conv_backward_chunks(...), q < 27 the conv-weight terms, q = 27 the
+ * threshold term, and d_thr / d_weight are not written -- finish with stages = 2 (same arguments) or hand the
+ * partials to nnue_sgd_step, whose norm launch then carries the second stage. */
 int64_t nnue_ste_conv_backward_scratch(int B, int fps, int Gh, int Gw);
+int64_t nnue_ste_conv_backward_chunks(int B, int fps, int Gh, int Gw);
 int nnue_ste_conv_backward(const float* images, const float* conv_out, const float* thr,
                            const float* d_conv_out, int B, int H, int W, int fps, int stride,
                            float* d_thr, float* d_weight, void* scratch, int64_t scratch_bytes,
-                           nnue_stream_t stream);
+                           int stages, nnue_stream_t stream);
 
 /* ---- FeatureTransformer ------------------------------------------------------- */
 
@@ -342,12 +347,17 @@ int nnue_engine_evaluate_logits(const nnue_engine_model* m, const float* images,
  *   norm = ||g||_2 ; c = min(1, max_norm/(norm+1e-6)) if max_norm > 0 else 1
  *   g <- c*g + wd*p ; m <- first_step ? g : momentum*m + g ; p <- p - lr*m
  * norm_out (device float, may be NULL) receives the pre-clip norm.  Deterministic
- * two-stage norm; scratch >= nnue_sgd_scratch(count) bytes. */
+ * two-stage norm; scratch >= nnue_sgd_scratch(count) bytes.
+ * ste_partial != NULL: the second stage of a deferred nnue_ste_conv_backward (stages = 1; nnue.py:28-54) runs as extra
+ * workgroups of the norm launch: d_thr[c] / d_weight[c*27+q] are summed from ste_partial (same order as stage 2, same
+ * bits), written, and enter the norm.  ste_d_thr and ste_d_weight must lie in grads and together form its first
+ * elements (a multiple of 4 of them); ste_fps * 28 <= 4096.  All five are NULL / 0 otherwise. */
 int64_t nnue_sgd_scratch(int64_t count);
 int nnue_sgd_step(float* params, float* grads, float* momentum_buf, int64_t count,
                   float lr, float momentum, float weight_decay, float max_norm, float grad_scale,
                   int first_step, float* norm_out, void* scratch, int64_t scratch_bytes,
-                  nnue_stream_t stream);
+                  const float* ste_partial, int ste_chunks, int ste_fps,
+                  float* ste_d_thr, float* ste_d_weight, nnue_stream_t stream);
 
 /* ---- input pipeline ------------------------------------------------------------------------------
  * One batch of GenericVisionDataset.__getitem__ + collate (data/datasets.py:173-195, :358-372) from a uint8

@@ -499,11 +499,17 @@ extern "C" int64_t nnue_ste_conv_backward_scratch(int B, int fps, int Gh, int Gw
   return blocks * fps * 28 * (int64_t)sizeof(float);
 }
 
+extern "C" int64_t nnue_ste_conv_backward_chunks(int B, int fps, int Gh, int Gw) {
+  if (B <= 0 || fps <= 0 || Gh <= 0 || Gw <= 0) return 0;
+  return fps <= 64 ? ste_mfma_blocks((int64_t)B * Gh * Gw) : ste_chunks(B, fps);
+}
+
 extern "C" int nnue_ste_conv_backward(const float* images, const float* conv_out, const float* thr,
                                       const float* d_conv_out, int B, int H, int W, int fps, int stride, float* d_thr,
-                                      float* d_weight, void* scratch, int64_t scratch_bytes, nnue_stream_t stream) {
+                                      float* d_weight, void* scratch, int64_t scratch_bytes, int stages, nnue_stream_t stream) {
   NNUE_REQUIRE(images && conv_out && thr && d_conv_out && scratch, NNUE_E_ARG, "nnue_ste_conv_backward: null pointer");
   NNUE_REQUIRE(d_thr || d_weight, NNUE_E_ARG, "nnue_ste_conv_backward: both outputs are null");
+  NNUE_REQUIRE(stages >= 1 && stages <= 3, NNUE_E_ARG, "nnue_ste_conv_backward: stages = 1 (partials) | 2 (final sums)");
   NNUE_REQUIRE(B > 0 && H > 0 && W > 0 && fps > 0 && stride > 0, NNUE_E_ARG,
                "nnue_ste_conv_backward: B=%d H=%d W=%d fps=%d stride=%d must be positive", B, H, W, fps, stride);
   const int Gh = (H - 1) / stride + 1, Gw = (W - 1) / stride + 1;
@@ -519,6 +525,7 @@ extern "C" int nnue_ste_conv_backward(const float* images, const float* conv_out
                  "nnue_ste_conv_backward: too many positions");
     const int tiles = (int)((NP + kStePos - 1) / kStePos);
     chunks = (int)ste_mfma_blocks(NP);
+    if (stages & 1) {
 #define NNUE_STE_LAUNCH(MT)                                                                                              \
   hipLaunchKernelGGL(ste_conv_backward_mfma<MT>, dim3(chunks), dim3(256), 0, s, images, conv_out, thr, d_conv_out, B, H, W, \
                      fps, stride, Gh, Gw, tiles, partial)
@@ -529,13 +536,16 @@ extern "C" int nnue_ste_conv_backward(const float* images, const float* conv_out
       default: NNUE_STE_LAUNCH(4); break;
     }
 #undef NNUE_STE_LAUNCH
+    }
   } else {
     chunks = ste_chunks(B, fps);
     const int spc = (B + chunks - 1) / chunks;
     NNUE_REQUIRE((long long)spc * Gh * Gw < (1ll << 31), NNUE_E_SHAPE, "nnue_ste_conv_backward: chunk too large");
-    hipLaunchKernelGGL(ste_conv_backward_stage1, dim3(fps, chunks), dim3(256), 0, s, images, conv_out, thr, d_conv_out, B, H,
-                       W, fps, stride, Gh, Gw, spc, partial);
+    if (stages & 1)
+      hipLaunchKernelGGL(ste_conv_backward_stage1, dim3(fps, chunks), dim3(256), 0, s, images, conv_out, thr, d_conv_out, B, H,
+                         W, fps, stride, Gh, Gw, spc, partial);
   }
-  hipLaunchKernelGGL(ste_conv_backward_stage2, dim3((fps * 28 + 3) / 4), dim3(256), 0, s, partial, chunks, fps, d_thr, d_weight);
+  if (stages & 2)
+    hipLaunchKernelGGL(ste_conv_backward_stage2, dim3((fps * 28 + 3) / 4), dim3(256), 0, s, partial, chunks, fps, d_thr, d_weight);
   return nnue_launch_status("nnue_ste_conv_backward");
 }

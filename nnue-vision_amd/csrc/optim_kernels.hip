@@ -86,10 +86,11 @@ constexpr int kNormBlocks = 1024;
 
 // Block partial of sum (g * scale)^2: 16-byte loads, four independent chains per thread (the 268 MB gradient of
 // the 224x224 configuration is one streaming read; a dependent scalar chain reached only 1.25 TB/s).
-__device__ __forceinline__ float sqnorm_block_partial(const float* __restrict__ g, int64_t count, float scale, float* red) {
+__device__ __forceinline__ float sqnorm_block_partial(const float* __restrict__ g, int64_t count, float scale, float* red,
+                                                      int blk, int nblk) {
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)nblk * 256;
+  const int64_t tid = (int64_t)blk * 256 + threadIdx.x;
   const int64_t n4 = ((reinterpret_cast<uintptr_t>(g) & 15) == 0) ? (count >> 2) : 0;
   const float4* __restrict__ g4 = reinterpret_cast<const float4*>(g);
   auto sq = [&](float4 v, float a) {
@@ -115,8 +116,51 @@ __device__ __forceinline__ float sqnorm_block_partial(const float* __restrict__ 
 __global__ __launch_bounds__(256) void sqnorm_stage1(const float* __restrict__ g, int64_t count, float scale,
                                                      float* __restrict__ partial) {
   __shared__ float red[4];
-  const float v = sqnorm_block_partial(g, count, scale, red);
+  const float v = sqnorm_block_partial(g, count, scale, red, blockIdx.x, gridDim.x);
   if (threadIdx.x == 0) partial[blockIdx.x] = v;
+}
+
+// The norm launch with the second stage of a deferred nnue_ste_conv_backward riding in it (feature_kernels.hip,
+// ste_conv_backward_stage2: one wave per (channel, term), lanes stride over the output's contiguous run of partials,
+// the same sums in the same order).  Workgroups [0, s2_blocks) write d_thr / d_weight -- the first `skip` elements of
+// g -- and leave the squares of their four outputs in partial[kNormBlocks + block]; the others are the plain norm
+// workgroups over g[skip:].
+__global__ __launch_bounds__(256) void sqnorm_stage1_ste(const float* __restrict__ g, int64_t count, float scale,
+                                                         float* __restrict__ partial, const float* __restrict__ ste_partial,
+                                                         int chunks, int fps, float* __restrict__ d_thr,
+                                                         float* __restrict__ d_weight, int s2_blocks, int64_t skip) {
+  __shared__ float red[4];
+  if ((int)blockIdx.x >= s2_blocks) {
+    const float v = sqnorm_block_partial(g + skip, count - skip, scale, red, (int)blockIdx.x - s2_blocks, kNormBlocks);
+    if (threadIdx.x == 0) partial[blockIdx.x - s2_blocks] = v;
+    return;
+  }
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  float sq = 0.0f;
+  if (o < fps * 28) {
+    const int c = o / 28, q = o - c * 28;
+    const float* __restrict__ run = ste_partial + (size_t)o * chunks;
+    float acc = 0.0f;
+    int k = lane;
+    for (; k + 7 * 64 < chunks; k += 8 * 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = run[k + 64 * u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; k < chunks; k += 64) acc += run[k];
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      if (q == 27) d_thr[c] = -acc;
+      else d_weight[c * 27 + q] = acc;
+    }
+    sq = (acc * scale) * (acc * scale);
+  }
+  if (lane == 0) red[threadIdx.x >> 6] = sq;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[kNormBlocks + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // Every block re-derives the norm from the kNormBlocks partials (4 KiB, L2-resident) in the same
@@ -164,7 +208,7 @@ __global__ __launch_bounds__(256) void sqnorm_stage1_count(const float* __restri
                                                            float* __restrict__ partial, int* __restrict__ step_counter) {
   __shared__ float red[4];
   if (blockIdx.x == 0 && threadIdx.x == 0) step_counter[0] += 1;
-  const float v = sqnorm_block_partial(g, count, scale, red);
+  const float v = sqnorm_block_partial(g, count, scale, red, blockIdx.x, gridDim.x);
   if (threadIdx.x == 0) partial[blockIdx.x] = v;
 }
 
@@ -237,14 +281,17 @@ extern "C" int nnue_cross_entropy(const float* logits, const int64_t* labels, in
   return nnue_launch_status("nnue_cross_entropy");
 }
 
+constexpr int kSteRideBlocks = 1024;  // room for the second-stage workgroups of a deferred STE sum (fps * 28 <= 4096)
+
 extern "C" int64_t nnue_sgd_scratch(int64_t count) {
   (void)count;
-  return kNormBlocks * (int64_t)sizeof(float);
+  return (kNormBlocks + kSteRideBlocks) * (int64_t)sizeof(float);
 }
 
 extern "C" int nnue_sgd_step(float* params, float* grads, float* momentum_buf, int64_t count, float lr, float momentum,
                              float weight_decay, float max_norm, float grad_scale, int first_step, float* norm_out,
-                             void* scratch, int64_t scratch_bytes, nnue_stream_t stream) {
+                             void* scratch, int64_t scratch_bytes, const float* ste_partial, int ste_chunks, int ste_fps,
+                             float* ste_d_thr, float* ste_d_weight, nnue_stream_t stream) {
   NNUE_REQUIRE(params && grads && scratch, NNUE_E_ARG, "nnue_sgd_step: null pointer");
   NNUE_REQUIRE(count > 0, NNUE_E_ARG, "nnue_sgd_step: count must be positive");
   NNUE_REQUIRE(momentum == 0.0f || momentum_buf, NNUE_E_ARG, "nnue_sgd_step: momentum %g needs a momentum buffer", momentum);
@@ -252,12 +299,31 @@ extern "C" int nnue_sgd_step(float* params, float* grads, float* momentum_buf, i
                (long long)scratch_bytes, (long long)nnue_sgd_scratch(count));
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* partial = static_cast<float*>(scratch);
-  if (max_norm > 0.0f || norm_out)
+  int nparts = kNormBlocks;
+  if (ste_partial) {
+    // the deferred sums own the first `skip` elements of grads: [d_thr | d_weight] in either order, nothing else
+    NNUE_REQUIRE(ste_d_thr && ste_d_weight && ste_chunks > 0 && ste_fps > 0 && ste_fps * 28 <= 4 * kSteRideBlocks, NNUE_E_ARG,
+                 "nnue_sgd_step: deferred STE sums need d_thr, d_weight, chunks > 0 and fps * 28 <= %d", 4 * kSteRideBlocks);
+    const float* lo = ste_d_thr < ste_d_weight ? ste_d_thr : ste_d_weight;
+    const float* hi_t = ste_d_thr + ste_fps;
+    const float* hi_w = ste_d_weight + (size_t)ste_fps * 27;
+    const float* hi = hi_t > hi_w ? hi_t : hi_w;
+    const int64_t skip = nnue_round_up(hi - grads, 4);
+    NNUE_REQUIRE(lo == grads && skip <= count && skip <= nnue_round_up(ste_fps, 4) + nnue_round_up((int64_t)ste_fps * 27, 4) + 8, NNUE_E_ARG,
+                 "nnue_sgd_step: deferred STE outputs must be the first elements of grads");
+    const int s2_blocks = (ste_fps * 28 + 3) / 4;
+    // padding between / after the two outputs is never written by the sums: it enters neither the norm nor is it read
+    // before the update multiplies it -- keep it zero (the flat gradient buffer's padding is zero-initialised)
+    hipLaunchKernelGGL(sqnorm_stage1_ste, dim3(kNormBlocks + s2_blocks), dim3(256), 0, s, grads, count, grad_scale, partial, ste_partial,
+                       ste_chunks, ste_fps, ste_d_thr, ste_d_weight, s2_blocks, skip);
+    nparts = kNormBlocks + s2_blocks;
+  } else if (max_norm > 0.0f || norm_out) {
     hipLaunchKernelGGL(sqnorm_stage1, dim3(kNormBlocks), dim3(256), 0, s, grads, count, grad_scale, partial);
+  }
   int blocks = (int)((count + 1023) / 1024);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(sgd_apply_kernel, dim3(blocks), dim3(256), 0, s, params, grads, momentum == 0.0f ? nullptr : momentum_buf,
-                     count, lr, momentum, weight_decay, max_norm, grad_scale, first_step, partial, kNormBlocks, norm_out);
+                     count, lr, momentum, weight_decay, max_norm, grad_scale, first_step, partial, nparts, norm_out);
   return nnue_launch_status("nnue_sgd_step");
 }
 

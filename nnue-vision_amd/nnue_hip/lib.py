@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -29,8 +29,9 @@ SIGNATURES = {
                                         _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_p]),
     "nnue_act_to_padded": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
     "nnue_ste_conv_backward_scratch": (_c_i64, [_c_int, _c_int, _c_int, _c_int]),
+    "nnue_ste_conv_backward_chunks": (_c_i64, [_c_int, _c_int, _c_int, _c_int]),
     "nnue_ste_conv_backward": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int,
-                                        _c_p, _c_p, _c_p, _c_i64, _c_p]),
+                                        _c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
     "nnue_ft_prepare": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_p]),
     "nnue_ft_forward": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p]),
     "nnue_ft_backward_weight": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
@@ -80,7 +81,7 @@ SIGNATURES = {
     "nnue_adam_step": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f,
                                 _c_p, _c_p, _c_i64, _c_p]),
     "nnue_sgd_step": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_int,
-                               _c_p, _c_p, _c_i64, _c_p]),
+                               _c_p, _c_p, _c_i64, _c_p, _c_int, _c_int, _c_p, _c_p, _c_p]),
 }
 
 _lib: Optional[ctypes.CDLL] = None
@@ -258,7 +259,9 @@ def act_to_padded(act: ActList, width: int) -> Tuple[torch.Tensor, torch.Tensor]
 
 def ste_conv_backward(images, conv_out, thr, d_conv_out, stride: int,
                       d_thr: Optional[torch.Tensor] = None, d_weight: Optional[torch.Tensor] = None,
-                      scratch: Optional[torch.Tensor] = None):
+                      scratch: Optional[torch.Tensor] = None, stages: int = 3):
+    """stages=1 leaves the per-workgroup partials at the start of `scratch` (finish with stages=2 or hand them to
+    sgd_step(ste=...), whose norm launch then carries the second stage)."""
     images = _need(images, torch.float32, "images")
     b, _, h, w = images.shape
     fps = conv_out.shape[1]
@@ -275,9 +278,14 @@ def ste_conv_backward(images, conv_out, thr, d_conv_out, stride: int,
     if scratch is None:
         scratch = torch.empty((need,), dtype=torch.uint8, device=dev)
     _call("nnue_ste_conv_backward", images.data_ptr(), conv_out.data_ptr(), thr.data_ptr(), d_conv_out.data_ptr(),
-          b, h, w, fps, stride, d_thr.data_ptr(), d_weight.data_ptr(), scratch.data_ptr(), scratch.numel(),
+          b, h, w, fps, stride, d_thr.data_ptr(), d_weight.data_ptr(), scratch.data_ptr(), scratch.numel(), int(stages),
           _stream(images))
     return d_thr, d_weight
+
+
+def ste_conv_backward_chunks(b: int, fps: int, gh: int, gw: int) -> int:
+    """Partials per output a stages=1 call leaves in its scratch."""
+    return int(load().nnue_ste_conv_backward_chunks(b, fps, gh, gw))
 
 
 # ---------------------------------------------------------------------------- FeatureTransformer
@@ -789,14 +797,21 @@ def sgd_scratch_bytes(count: int) -> int:
 
 def sgd_step(params: torch.Tensor, grads: torch.Tensor, momentum_buf: Optional[torch.Tensor], lr: float,
              momentum: float, weight_decay: float, max_norm: float, grad_scale: float, first_step: bool,
-             norm_out: Optional[torch.Tensor], scratch: torch.Tensor) -> None:
+             norm_out: Optional[torch.Tensor], scratch: torch.Tensor, ste=None) -> None:
+    """ste = (partial scratch of ste_conv_backward(stages=1), chunks, fps, d_thr, d_weight): the deferred second stage
+    runs inside the norm launch; d_thr / d_weight must be the first elements of `grads`."""
     params = _need(params, torch.float32, "flat params")
     grads = _need(grads, torch.float32, "flat grads", tuple(params.shape))
     if momentum_buf is not None:
         _need(momentum_buf, torch.float32, "momentum buffer", tuple(params.shape))
+    if ste is not None:
+        part, chunks, fps, d_thr, d_weight = ste
+        ste_args = (part.data_ptr(), int(chunks), int(fps), d_thr.data_ptr(), d_weight.data_ptr())
+    else:
+        ste_args = (None, 0, 0, None, None)
     _call("nnue_sgd_step", params.data_ptr(), grads.data_ptr(), _ptr(momentum_buf), params.numel(), float(lr),
           float(momentum), float(weight_decay), float(max_norm), float(grad_scale), int(bool(first_step)),
-          _ptr(norm_out), scratch.data_ptr(), scratch.numel(), _stream(params))
+          _ptr(norm_out), scratch.data_ptr(), scratch.numel(), *ste_args, _stream(params))
 
 
 def adam_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,

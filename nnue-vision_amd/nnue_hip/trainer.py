@@ -187,6 +187,11 @@ class NnueTrainer:
                                             lib.classifier_train_scratch_bytes(B, self.L1, self.L2, self.L3, self.C)),), **u8)
         self.ste_scratch = torch.empty((max(16, lib.load().nnue_ste_conv_backward_scratch(B, self.fps, self.gh, self.gw)),), **u8)
         self.sgd_scratch = torch.empty((lib.sgd_scratch_bytes(self.layout.count),), **u8)
+        # single rank + SGD: the second stage of the STE / conv-weight gradient sum rides in the optimizer's norm launch
+        # (with collectives the gradients must be complete before the all-reduce)
+        self.defer_ste = (not self.dp.collectives and optimizer == "sgd" and os.environ.get("NNUE_DEFER_STE", "1") != "0"
+                          and self.fps * 28 <= 4096 and self.layout.names[:2] == ["visual_threshold", "conv.weight"])
+        self.ste_chunks = lib.ste_conv_backward_chunks(B, self.fps, self.gh, self.gw)
         self.fuse_l1 = (self.use_mfma and os.environ.get("NNUE_FUSE_L1", "1") != "0"
                         and lib.ftm_forward_l1_supported(B, self.F, self.P, self.L1, self.L2))
         self.steps_done = 0
@@ -287,7 +292,8 @@ class NnueTrainer:
             else:
                 lib.ft_backward_values(self.d_ft, p["input.weight"], self.act, self.P, dst=self.d_conv_out)
             lib.ste_conv_backward(self.images, self.conv_out, p["visual_threshold"], self.d_conv_out, self.stride,
-                                  d_thr=g["visual_threshold"], d_weight=g["conv.weight"], scratch=self.ste_scratch)
+                                  d_thr=g["visual_threshold"], d_weight=g["conv.weight"], scratch=self.ste_scratch,
+                                  stages=1 if self.defer_ste else 3)
         else:
             raise KeyError(name)
 
@@ -307,8 +313,10 @@ class NnueTrainer:
                           self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm, scale, self.grad_norm,
                           self.sgd_scratch)
         else:
+            ste = ((self.ste_scratch, self.ste_chunks, self.fps, self.g["visual_threshold"], self.g["conv.weight"])
+                   if self.defer_ste else None)
             lib.sgd_step(self.flat_params, self.flat_grads, self.flat_momentum, self.lr, self.momentum, self.weight_decay,
-                         self.max_grad_norm, scale, first, self.grad_norm, self.sgd_scratch)
+                         self.max_grad_norm, scale, first, self.grad_norm, self.sgd_scratch, ste=ste)
 
     def _optimizer_buffers(self):
         return [t for t in (self.flat_momentum, self.flat_exp_avg, self.flat_exp_avg_sq, self.adam_step_count) if t is not None]

@@ -374,3 +374,49 @@ def test_classifier_train_step_leaves_dw1_to_the_rider(hip, shape):
     assert_close_grad(ref[3][0].cpu(), d_z1.t() @ l0, "d_w1 from the published d_z1", rtol=2e-5)
     with pytest.raises(hip.NnueHipError):
         hip.classifier_train_step(x, True, *p, labels, phases=23)  # 4 and 16 exclude each other
+
+
+@pytest.mark.parametrize("shape", [(64, 32, 32, 8, 3), (7, 40, 40, 3, 4), (16, 64, 64, 20, 7)])
+def test_deferred_ste_sums_ride_in_the_norm_launch(hip, shape):
+    """nnue_ste_conv_backward(stages=1) + nnue_sgd_step(ste=...) against the plain two calls: d_thr / d_weight bitwise
+    (same sums, same order), norm and updated parameters within float rounding (other partition of the partials)."""
+    b, h, w, fps, stride = shape
+    gen = torch.Generator().manual_seed(b + fps)
+    images = g(torch.randn(b, 3, h, w, generator=gen))
+    gh, gw = hip.conv_out_hw(h, w, stride)
+    conv_out = g(torch.randn(b, fps, gh, gw, generator=gen))
+    thr = g(torch.randn(fps, generator=gen) * 0.1)
+    d_conv = g(torch.randn(b, fps, gh, gw, generator=gen) / b)
+    n_thr, n_w = (fps + 3) // 4 * 4, (fps * 27 + 3) // 4 * 4
+    count = n_thr + n_w + 4096 + 4
+    base_g = torch.zeros(count)
+    base_g[n_thr + n_w:] = torch.randn(4096 + 4, generator=gen)
+    params0 = g(torch.randn(count, generator=gen))
+
+    def run(defer):
+        grads, params, mom = g(base_g.clone()), params0.clone(), torch.zeros(count, device=DEV)
+        d_thr, d_w = grads[:fps], grads[n_thr:n_thr + fps * 27].view(fps, 3, 3, 3)
+        scratch = torch.empty((max(16, hip.load().nnue_ste_conv_backward_scratch(b, fps, gh, gw)),), dtype=torch.uint8, device=DEV)
+        norm = torch.zeros((), device=DEV)
+        sgd_scratch = torch.empty((hip.sgd_scratch_bytes(count),), dtype=torch.uint8, device=DEV)
+        hip.ste_conv_backward(images, conv_out, thr, d_conv, stride, d_thr=d_thr, d_weight=d_w, scratch=scratch, stages=1 if defer else 3)
+        ste = (scratch, hip.ste_conv_backward_chunks(b, fps, gh, gw), fps, d_thr, d_w) if defer else None
+        hip.sgd_step(params, grads, mom, 0.05, 0.9, 1e-4, 1.0, 0.5, True, norm, sgd_scratch, ste=ste)
+        return grads, params, float(norm)
+
+    g0, p0, n0 = run(False)
+    g1, p1, n1 = run(True)
+    assert torch.equal(g0, g1)
+    assert abs(n0 - n1) <= 1e-5 * n0
+    assert_close_grad(p1, p0, "updated parameters", rtol=1e-5)
+    # stage 2 on its own finishes the same partials
+    grads = g(base_g.clone())
+    d_thr, d_w = grads[:fps], grads[n_thr:n_thr + fps * 27].view(fps, 3, 3, 3)
+    scratch = torch.empty((max(16, hip.load().nnue_ste_conv_backward_scratch(b, fps, gh, gw)),), dtype=torch.uint8, device=DEV)
+    hip.ste_conv_backward(images, conv_out, thr, d_conv, stride, d_thr=d_thr, d_weight=d_w, scratch=scratch, stages=1)
+    hip.ste_conv_backward(images, conv_out, thr, d_conv, stride, d_thr=d_thr, d_weight=d_w, scratch=scratch, stages=2)
+    assert torch.equal(grads[:n_thr + n_w], g0[:n_thr + n_w])
+    with pytest.raises(hip.NnueHipError):  # outputs that are not the head of the gradient buffer
+        hip.sgd_step(p0, g0, torch.zeros(count, device=DEV), 0.05, 0.9, 0.0, 1.0, 1.0, True, None,
+                     torch.empty((hip.sgd_scratch_bytes(count),), dtype=torch.uint8, device=DEV),
+                     ste=(scratch, 4, fps, g0[8:8 + fps], g0[n_thr:n_thr + fps * 27]))
