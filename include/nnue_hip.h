@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 16
+#define NNUE_HIP_ABI_VERSION 17
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -228,6 +228,7 @@ int nnue_ftm_backward_values(const uint8_t* bits, const float* d_out, const floa
                              int B, int F, int P, int L1, float* d_conv_out, nnue_stream_t stream);
 
 int nnue_ftm_backward_cw_supported(int B, int F, int P, int L1, int L2); /* shapes whose nnue_ftm_backward takes d_w1 */
+int64_t nnue_ftm_backward_sq_count(int B, int F, int P, int L1); /* floats nnue_ftm_backward's sq_partial receives; 0: none */
 
 /* nnue_ftm_backward_weight + nnue_ftm_backward_values as ONE launch (autograd of nnue.py:702-708, :628-633): the
  * two products and the tail rows are independent, so their workgroups share the chip.  Same results, bit for bit,
@@ -235,10 +236,15 @@ int nnue_ftm_backward_cw_supported(int B, int F, int P, int L1, int L2); /* shap
  * Optional rider (d_w1 != NULL, shapes: nnue_ftm_backward_cw_supported, declared above): the weight gradient of the
  * classifier's first Linear, d_w1[L2][L1] = d_z1^T l0 (autograd of nnue.py:728-730 through the pairwise block
  * nnue.py:660-666), from ft[B][L1] (the FeatureTransformer output) and d_z1[B][L2] (left in the classifier's scratch
- * by nnue_classifier_train_step, at nnue_classifier_train_dz1_offset); pair with phases bit 16 there. */
+ * by nnue_classifier_train_step, at nnue_classifier_train_dz1_offset); pair with phases bit 16 there.
+ * sq_partial (may be NULL): nnue_ftm_backward_sq_count(B, F, P, L1) floats (declared above) that receive, per
+ * weight-gradient tile, the sum of the squares of the elements it wrote -- together the squared norm of
+ * d_weight[0 .. min(F-1, P)) -- so that nnue_sgd_step (ext_partial) need not read those rows again for
+ * clip_grad_norm_ (train.py:363-364). */
 int nnue_ftm_backward(const uint8_t* bits, const float* sink, const float* d_out, const float* weight,
                       int B, int F, int P, int L1, float* d_weight, float* d_bias, float* d_conv_out,
-                      const float* ft, const float* d_z1, int L2, float* d_w1, nnue_stream_t stream);
+                      const float* ft, const float* d_z1, int L2, float* d_w1, float* sq_partial,
+                      nnue_stream_t stream);
 
 /* ---- pairwise product + SimpleClassifier -------------------------------------- */
 
@@ -351,13 +357,18 @@ int nnue_engine_evaluate_logits(const nnue_engine_model* m, const float* images,
  * ste_partial != NULL: the second stage of a deferred nnue_ste_conv_backward (stages = 1; nnue.py:28-54) runs as extra
  * workgroups of the norm launch: d_thr[c] / d_weight[c*27+q] are summed from ste_partial (same order as stage 2, same
  * bits), written, and enter the norm.  ste_d_thr and ste_d_weight must lie in grads and together form its first
- * elements (a multiple of 4 of them); ste_fps * 28 <= 4096.  All five are NULL / 0 otherwise. */
+ * elements (a multiple of 4 of them); ste_fps * 28 <= 4096.  All five are NULL / 0 otherwise.
+ * ext_partial != NULL: ext_count sums of squares (unscaled) that a producer formed for grads[ext_lo, ext_hi) (multiples of
+ * 4, e.g. nnue_ftm_backward's sq_partial for the FeatureTransformer weight rows): the norm launch skips that range and
+ * the partials enter the norm in index order, multiplied by grad_scale^2.  ext_count <= 65536. */
 int64_t nnue_sgd_scratch(int64_t count);
 int nnue_sgd_step(float* params, float* grads, float* momentum_buf, int64_t count,
                   float lr, float momentum, float weight_decay, float max_norm, float grad_scale,
                   int first_step, float* norm_out, void* scratch, int64_t scratch_bytes,
                   const float* ste_partial, int ste_chunks, int ste_fps,
-                  float* ste_d_thr, float* ste_d_weight, nnue_stream_t stream);
+                  float* ste_d_thr, float* ste_d_weight,
+                  const float* ext_partial, int ext_count, int64_t ext_lo, int64_t ext_hi,
+                  nnue_stream_t stream);
 
 /* ---- input pipeline ------------------------------------------------------------------------------
  * One batch of GenericVisionDataset.__getitem__ + collate (data/datasets.py:173-195, :358-372) from a uint8

@@ -70,6 +70,7 @@ struct FwdEpi {  // out = acc + bias + sink[b] * weight[F-1]   (or a split-K sla
   static constexpr bool kAU8 = true;  // operand A is the byte map
   static constexpr bool kFusedL1 = false;
   static constexpr bool kBPair = false;
+  static constexpr bool kSq = false;
   const float* __restrict__ bias;
   const float* __restrict__ w_last;  // weight row F-1
   const float* __restrict__ sink;
@@ -87,8 +88,10 @@ struct BwwEpi {  // d_weight rows with a position of their own
   static constexpr bool kAU8 = true;
   static constexpr bool kFusedL1 = false;
   static constexpr bool kBPair = false;
+  static constexpr bool kSq = true;  // can leave the sum of squares of its tile (gradient-norm partial)
   float* __restrict__ d_weight;
   int L1;
+  float* __restrict__ sq;  // NULL or one float per tile: sum of the squares of the tile's stored elements
   __device__ __forceinline__ float2 col(int) const { return make_float2(0.f, 0.f); }
   __device__ __forceinline__ float pre(int, int) const { return 0.0f; }
   __device__ __forceinline__ void store(int m, int n, float v, float2, float, int) const { d_weight[(size_t)m * L1 + n] = v; }
@@ -98,6 +101,7 @@ struct ValEpi {  // d_conv_out = acc where the position is active, else 0
   static constexpr bool kAU8 = false;
   static constexpr bool kFusedL1 = false;
   static constexpr bool kBPair = false;
+  static constexpr bool kSq = false;
   const uint8_t* __restrict__ bits;
   float* __restrict__ d_conv_out;
   int P;
@@ -116,6 +120,7 @@ struct CwEpi {
   static constexpr bool kAU8 = false;
   static constexpr bool kFusedL1 = false;
   static constexpr bool kBPair = true;
+  static constexpr bool kSq = false;
   float* __restrict__ d_w1;  // [L2][L1]
   int L1, half;
   __device__ __forceinline__ float2 col(int) const { return make_float2(0.f, 0.f); }
@@ -132,6 +137,7 @@ struct FwdL1Epi {
   static constexpr bool kAU8 = true;
   static constexpr bool kFusedL1 = true;
   static constexpr bool kBPair = false;
+  static constexpr bool kSq = false;
   const float* __restrict__ bias;
   const float* __restrict__ w_last;
   const float* __restrict__ sink;
@@ -411,6 +417,7 @@ __device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& m
         pre[i][t][e] = (m < M && n < N) ? epi.pre(m, n) : 0.0f;
       }
   }
+  float sqacc = 0.0f;
 #pragma unroll
   for (int t = 0; t < TN; ++t) {
     const int n = n_base + n0 + 16 * t + r;
@@ -419,8 +426,20 @@ __device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& m
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int m = m_base + m0 + 16 * i + 4 * q + e;
-        if (m < M && n < N) epi.store(m, n, acc[i][t][e], cv[t], pre[i][t][e], ks);
+        if (m < M && n < N) {
+          epi.store(m, n, acc[i][t][e], cv[t], pre[i][t][e], ks);
+          if constexpr (Epi::kSq) sqacc = fmaf(acc[i][t][e], acc[i][t][e], sqacc);
+        }
       }
+  }
+  if constexpr (Epi::kSq) {
+    if (epi.sq) {  // uniform; fixed order: lanes by butterfly, waves 0..3 (the K loop ended with a barrier: smem is free)
+#pragma unroll
+      for (int sh = 32; sh >= 1; sh >>= 1) sqacc += __shfl_xor(sqacc, sh);
+      if (lane == 0) smem[wave] = sqacc;
+      __syncthreads();
+      if (tid == 0) epi.sq[tile] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+    }
   }
   }
 }
@@ -740,8 +759,17 @@ extern "C" int nnue_ftm_forward(const uint8_t* bits, const float* sink, const fl
   return nnue_launch_status("nnue_ftm_forward");
 }
 
+namespace {
+int backward_weight_impl(const uint8_t* bits, const float* sink, const float* d_out, int B, int F, int P, int L1, float* d_weight,
+                         float* d_bias, float* sq, nnue_stream_t stream);
+}
 extern "C" int nnue_ftm_backward_weight(const uint8_t* bits, const float* sink, const float* d_out, int B, int F, int P, int L1,
                                         float* d_weight, float* d_bias, nnue_stream_t stream) {
+  return backward_weight_impl(bits, sink, d_out, B, F, P, L1, d_weight, d_bias, nullptr, stream);
+}
+namespace {
+int backward_weight_impl(const uint8_t* bits, const float* sink, const float* d_out, int B, int F, int P, int L1, float* d_weight,
+                         float* d_bias, float* sq, nnue_stream_t stream) {
   NNUE_REQUIRE(bits && sink && d_out, NNUE_E_ARG, "nnue_ftm_backward_weight: null pointer");
   NNUE_REQUIRE(d_weight || d_bias, NNUE_E_ARG, "nnue_ftm_backward_weight: both outputs are null");
   NNUE_REQUIRE(shape_ok(B, F, P, L1), NNUE_E_ARG, "nnue_ftm_backward_weight: B=%d F=%d P=%d L1=%d out of range", B, F, P, L1);
@@ -752,12 +780,14 @@ extern "C" int nnue_ftm_backward_weight(const uint8_t* bits, const float* sink, 
   if (d_weight && direct > 0) {
     const Shape s = plan(direct, L1, B, false, false);
     launch<false, false>(st, s, Mat{bits, (unsigned)((size_t)B * P), P, kIntMax, kIntMax},
-                         Mat{d_out, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, kIntMax}, BwwEpi{d_weight, L1}, direct, L1, B);
+                         Mat{d_out, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, kIntMax}, BwwEpi{d_weight, L1, s.ksplit == 1 ? sq : nullptr},
+                         direct, L1, B);
   }
   const TailRows t = tail_rows(d_out, sink, B, L1, direct, F, d_weight, d_bias);
   hipLaunchKernelGGL(ftm_tail_rows_kernel, dim3(t.col_blocks, 1 + t.zero_slices), dim3(256), 0, st, t);
   return nnue_launch_status("nnue_ftm_backward_weight");
 }
+}  // namespace
 
 extern "C" int nnue_ftm_backward_values(const uint8_t* bits, const float* d_out, const float* weight, int B, int F, int P, int L1,
                                         float* d_conv_out, nnue_stream_t stream) {
@@ -790,6 +820,22 @@ bool merged_backward_shape(int B, int F, int P, int L1, bool* big) {
 }
 }  // namespace
 
+// Number of squared-norm partials nnue_ftm_backward leaves (one per weight-gradient tile), 0 when the product is split
+// along K (never for this operand order today) or the shape is not taken.
+extern "C" int64_t nnue_ftm_backward_sq_count(int B, int F, int P, int L1) {
+  if (!nnue_ftm_supported(F, P, L1) || !shape_ok(B, F, P, L1)) return 0;
+  const int direct = (F - 1 < P) ? F - 1 : P;
+  if (direct <= 0) return 0;
+  bool big = false;
+  if (merged_backward_shape(B, F, P, L1, &big)) {
+    if (big) return (int64_t)((direct + 63) / 64) * ((L1 + 63) / 64);
+    const Shape s = plan(direct, L1, B, false, false);
+    return (int64_t)s.tiles_m * s.tiles_n;
+  }
+  const Shape s = plan(direct, L1, B, false, false);
+  return s.ksplit == 1 ? (int64_t)s.tiles_m * s.tiles_n : 0;
+}
+
 extern "C" int nnue_ftm_backward_cw_supported(int B, int F, int P, int L1, int L2) {
   bool big = false;
   return nnue_ftm_supported(F, P, L1) && shape_ok(B, F, P, L1) && merged_backward_shape(B, F, P, L1, &big) && L1 % 128 == 0 && L2 > 0 &&
@@ -798,7 +844,7 @@ extern "C" int nnue_ftm_backward_cw_supported(int B, int F, int P, int L1, int L
 
 extern "C" int nnue_ftm_backward(const uint8_t* bits, const float* sink, const float* d_out, const float* weight, int B, int F, int P,
                                  int L1, float* d_weight, float* d_bias, float* d_conv_out, const float* ft, const float* d_z1, int L2,
-                                 float* d_w1, nnue_stream_t stream) {
+                                 float* d_w1, float* sq_partial, nnue_stream_t stream) {
   NNUE_REQUIRE(bits && sink && d_out && weight && d_weight && d_bias && d_conv_out, NNUE_E_ARG, "nnue_ftm_backward: null pointer");
   const bool want_cw = d_w1 != nullptr;
   NNUE_REQUIRE(!want_cw || (ft && d_z1 && nnue_ftm_backward_cw_supported(B, F, P, L1, L2) && nnue_aligned16(ft) && nnue_aligned16(d_z1)),
@@ -821,12 +867,12 @@ extern "C" int nnue_ftm_backward(const uint8_t* bits, const float* sink, const f
   for (Shape* q : {&sw2, &sv2}) { q->cfg = 1; q->bm = 64; q->bn = 64; q->bk = 64; }
   sw2.tiles_m = (direct + 63) / 64; sw2.tiles_n = (L1 + 63) / 64; sv2.tiles_m = (B + 63) / 64; sv2.tiles_n = (P + 63) / 64;
   if (!pair_ok) {
-    const int rc = nnue_ftm_backward_weight(bits, sink, d_out, B, F, P, L1, d_weight, d_bias, stream);
+    const int rc = backward_weight_impl(bits, sink, d_out, B, F, P, L1, d_weight, d_bias, sq_partial, stream);
     return rc != NNUE_OK ? rc : nnue_ftm_backward_values(bits, d_out, weight, B, F, P, L1, d_conv_out, stream);
   }
   const Mat wa{bits, (unsigned)((size_t)B * P), P, kIntMax, kIntMax}, wb{d_out, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, kIntMax};
   const Mat va{d_out, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, L1}, vb{weight, (unsigned)((size_t)F * L1 * 4), L1, F - 1, kIntMax};
-  const BwwEpi we{d_weight, L1};
+  const BwwEpi we{d_weight, L1, sq_partial};
   const ValEpi ve{bits, d_conv_out, P};
   const TailRows t = tail_rows(d_out, sink, B, L1, direct, F, d_weight, d_bias);
   const Shape& swr = big_pair ? sw2 : sw;

@@ -113,10 +113,21 @@ __device__ __forceinline__ float sqnorm_block_partial(const float* __restrict__ 
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// The plain block partial over g[0, count) without [lo, hi) (a producer already summed that range; lo == hi: nothing
+// skipped).  Two passes through the same routine; the barrier between them protects the reduction buffer.
+__device__ __forceinline__ float sqnorm_block_partial_skip(const float* __restrict__ g, int64_t count, float scale, float* red, int blk,
+                                                           int nblk, int64_t lo, int64_t hi) {
+  if (lo >= hi) return sqnorm_block_partial(g, count, scale, red, blk, nblk);
+  const float a = sqnorm_block_partial(g, lo, scale, red, blk, nblk);
+  __syncthreads();
+  const float b = sqnorm_block_partial(g + hi, count - hi, scale, red, blk, nblk);
+  return a + b;
+}
+
 __global__ __launch_bounds__(256) void sqnorm_stage1(const float* __restrict__ g, int64_t count, float scale,
-                                                     float* __restrict__ partial) {
+                                                     float* __restrict__ partial, int64_t lo, int64_t hi) {
   __shared__ float red[4];
-  const float v = sqnorm_block_partial(g, count, scale, red, blockIdx.x, gridDim.x);
+  const float v = sqnorm_block_partial_skip(g, count, scale, red, blockIdx.x, gridDim.x, lo, hi);
   if (threadIdx.x == 0) partial[blockIdx.x] = v;
 }
 
@@ -128,10 +139,12 @@ __global__ __launch_bounds__(256) void sqnorm_stage1(const float* __restrict__ g
 __global__ __launch_bounds__(256) void sqnorm_stage1_ste(const float* __restrict__ g, int64_t count, float scale,
                                                          float* __restrict__ partial, const float* __restrict__ ste_partial,
                                                          int chunks, int fps, float* __restrict__ d_thr,
-                                                         float* __restrict__ d_weight, int s2_blocks, int64_t skip) {
+                                                         float* __restrict__ d_weight, int s2_blocks, int64_t skip, int64_t lo,
+                                                         int64_t hi) {
   __shared__ float red[4];
   if ((int)blockIdx.x >= s2_blocks) {
-    const float v = sqnorm_block_partial(g + skip, count - skip, scale, red, (int)blockIdx.x - s2_blocks, kNormBlocks);
+    const float v = sqnorm_block_partial_skip(g + skip, count - skip, scale, red, (int)blockIdx.x - s2_blocks, kNormBlocks,
+                                              lo > skip ? lo - skip : 0, hi > skip ? hi - skip : 0);
     if (threadIdx.x == 0) partial[blockIdx.x - s2_blocks] = v;
     return;
   }
@@ -169,13 +182,18 @@ __global__ __launch_bounds__(256) void sgd_apply_kernel(float* __restrict__ p, c
                                                         float* __restrict__ m, int64_t count, float lr, float momentum,
                                                         float wd, float max_norm, float scale, int first_step,
                                                         const float* __restrict__ partial, int nparts,
-                                                        float* __restrict__ norm_out) {
+                                                        float* __restrict__ norm_out, const float* __restrict__ ext_partial,
+                                                        int ext_count) {
   __shared__ double red[4];
   __shared__ float coef_s;
   float clip = 1.0f;
   if (max_norm > 0.0f || norm_out) {
     double acc = 0.0;
     for (int i = threadIdx.x; i < nparts; i += 256) acc += (double)partial[i];
+    if (ext_partial) {  // a producer's sums of squares (unscaled) of the range the norm launch skipped
+      const double s2 = (double)scale * (double)scale;
+      for (int i = threadIdx.x; i < ext_count; i += 256) acc += (double)ext_partial[i] * s2;
+    }
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -291,7 +309,8 @@ extern "C" int64_t nnue_sgd_scratch(int64_t count) {
 extern "C" int nnue_sgd_step(float* params, float* grads, float* momentum_buf, int64_t count, float lr, float momentum,
                              float weight_decay, float max_norm, float grad_scale, int first_step, float* norm_out,
                              void* scratch, int64_t scratch_bytes, const float* ste_partial, int ste_chunks, int ste_fps,
-                             float* ste_d_thr, float* ste_d_weight, nnue_stream_t stream) {
+                             float* ste_d_thr, float* ste_d_weight, const float* ext_partial, int ext_count, int64_t ext_lo,
+                             int64_t ext_hi, nnue_stream_t stream) {
   NNUE_REQUIRE(params && grads && scratch, NNUE_E_ARG, "nnue_sgd_step: null pointer");
   NNUE_REQUIRE(count > 0, NNUE_E_ARG, "nnue_sgd_step: count must be positive");
   NNUE_REQUIRE(momentum == 0.0f || momentum_buf, NNUE_E_ARG, "nnue_sgd_step: momentum %g needs a momentum buffer", momentum);
@@ -300,6 +319,13 @@ extern "C" int nnue_sgd_step(float* params, float* grads, float* momentum_buf, i
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* partial = static_cast<float*>(scratch);
   int nparts = kNormBlocks;
+  if (ext_partial) {
+    NNUE_REQUIRE(ext_count > 0 && ext_count <= 65536 && ext_lo >= 0 && ext_lo < ext_hi && ext_hi <= count && ext_lo % 4 == 0 && ext_hi % 4 == 0,
+                 NNUE_E_ARG, "nnue_sgd_step: producer partials need 0 < count <= 65536 and a range [lo, hi) of multiples of 4 inside grads");
+  } else {
+    ext_lo = ext_hi = 0;
+    ext_count = 0;
+  }
   if (ste_partial) {
     // the deferred sums own the first `skip` elements of grads: [d_thr | d_weight] in either order, nothing else
     NNUE_REQUIRE(ste_d_thr && ste_d_weight && ste_chunks > 0 && ste_fps > 0 && ste_fps * 28 <= 4 * kSteRideBlocks, NNUE_E_ARG,
@@ -309,21 +335,21 @@ extern "C" int nnue_sgd_step(float* params, float* grads, float* momentum_buf, i
     const float* hi_w = ste_d_weight + (size_t)ste_fps * 27;
     const float* hi = hi_t > hi_w ? hi_t : hi_w;
     const int64_t skip = nnue_round_up(hi - grads, 4);
-    NNUE_REQUIRE(lo == grads && skip <= count && skip <= nnue_round_up(ste_fps, 4) + nnue_round_up((int64_t)ste_fps * 27, 4) + 8, NNUE_E_ARG,
+    NNUE_REQUIRE((!ext_partial || ext_lo >= skip) && lo == grads && skip <= count && skip <= nnue_round_up(ste_fps, 4) + nnue_round_up((int64_t)ste_fps * 27, 4) + 8, NNUE_E_ARG,
                  "nnue_sgd_step: deferred STE outputs must be the first elements of grads");
     const int s2_blocks = (ste_fps * 28 + 3) / 4;
     // padding between / after the two outputs is never written by the sums: it enters neither the norm nor is it read
     // before the update multiplies it -- keep it zero (the flat gradient buffer's padding is zero-initialised)
     hipLaunchKernelGGL(sqnorm_stage1_ste, dim3(kNormBlocks + s2_blocks), dim3(256), 0, s, grads, count, grad_scale, partial, ste_partial,
-                       ste_chunks, ste_fps, ste_d_thr, ste_d_weight, s2_blocks, skip);
+                       ste_chunks, ste_fps, ste_d_thr, ste_d_weight, s2_blocks, skip, ext_lo, ext_hi);
     nparts = kNormBlocks + s2_blocks;
   } else if (max_norm > 0.0f || norm_out) {
-    hipLaunchKernelGGL(sqnorm_stage1, dim3(kNormBlocks), dim3(256), 0, s, grads, count, grad_scale, partial);
+    hipLaunchKernelGGL(sqnorm_stage1, dim3(kNormBlocks), dim3(256), 0, s, grads, count, grad_scale, partial, ext_lo, ext_hi);
   }
   int blocks = (int)((count + 1023) / 1024);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(sgd_apply_kernel, dim3(blocks), dim3(256), 0, s, params, grads, momentum == 0.0f ? nullptr : momentum_buf,
-                     count, lr, momentum, weight_decay, max_norm, grad_scale, first_step, partial, nparts, norm_out);
+                     count, lr, momentum, weight_decay, max_norm, grad_scale, first_step, partial, nparts, norm_out, ext_partial, ext_count);
   return nnue_launch_status("nnue_sgd_step");
 }
 

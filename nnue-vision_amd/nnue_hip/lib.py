@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -56,8 +56,9 @@ SIGNATURES = {
     "nnue_ftm_backward_weight": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
     "nnue_ftm_backward_values": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p]),
     "nnue_ftm_backward_cw_supported": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int]),
+    "nnue_ftm_backward_sq_count": (_c_i64, [_c_int, _c_int, _c_int, _c_int]),
     "nnue_ftm_backward": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p,
-                                   _c_p, _c_p, _c_int, _c_p, _c_p]),
+                                   _c_p, _c_p, _c_int, _c_p, _c_p, _c_p]),
     "nnue_classifier_scratch": (_c_i64, [_c_int, _c_int, _c_int, _c_int]),
     "nnue_classifier_forward": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_f,
                                          _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p,
@@ -81,7 +82,7 @@ SIGNATURES = {
     "nnue_adam_step": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f,
                                 _c_p, _c_p, _c_i64, _c_p]),
     "nnue_sgd_step": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_int,
-                               _c_p, _c_p, _c_i64, _c_p, _c_int, _c_int, _c_p, _c_p, _c_p]),
+                               _c_p, _c_p, _c_i64, _c_p, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_i64, _c_i64, _c_p]),
 }
 
 _lib: Optional[ctypes.CDLL] = None
@@ -622,6 +623,11 @@ def ftm_backward_values(d_out: torch.Tensor, weight: torch.Tensor, fm: FeatureMa
     return dst
 
 
+def ftm_backward_sq_count(b: int, f: int, p: int, l1: int) -> int:
+    """Floats ftm_backward's sq_partial receives (one sum of squares per weight-gradient tile); 0 = not available."""
+    return int(load().nnue_ftm_backward_sq_count(b, f, p, l1))
+
+
 def ftm_backward_cw_supported(b: int, f: int, p: int, l1: int, l2: int) -> bool:
     """Shapes whose merged backward launch can also carry the classifier's first-layer weight gradient."""
     return bool(load().nnue_ftm_backward_cw_supported(b, f, p, l1, l2))
@@ -629,7 +635,8 @@ def ftm_backward_cw_supported(b: int, f: int, p: int, l1: int, l2: int) -> bool:
 
 def ftm_backward(d_out: torch.Tensor, weight: torch.Tensor, fm: FeatureMatrix, d_weight: Optional[torch.Tensor] = None,
                  d_bias: Optional[torch.Tensor] = None, dst: Optional[torch.Tensor] = None, ft: Optional[torch.Tensor] = None,
-                 d_z1: Optional[torch.Tensor] = None, d_w1: Optional[torch.Tensor] = None):
+                 d_z1: Optional[torch.Tensor] = None, d_w1: Optional[torch.Tensor] = None,
+                 sq_partial: Optional[torch.Tensor] = None):
     """(d_weight, d_bias, d_conv_out) in one launch; bitwise the results of ftm_backward_weight + ftm_backward_values.
     With ft [B, L1], d_z1 [B, L2] and d_w1 [L2, L1] the launch also writes d_w1 = d_z1^T l0 (the pairwise block of ft)."""
     d_out = _need(d_out, torch.float32, "d_out")
@@ -654,7 +661,8 @@ def ftm_backward(d_out: torch.Tensor, weight: torch.Tensor, fm: FeatureMatrix, d
             raise ValueError("ftm_backward: ft / d_z1 / d_w1 shape mismatch")
     _call("nnue_ftm_backward", fm.bits.data_ptr(), fm.sink.data_ptr(), d_out.data_ptr(), weight.data_ptr(), b, fm.num_rows,
           fm.positions, l1, d_weight.data_ptr(), d_bias.data_ptr(), dst.data_ptr(),
-          _ptr(ft if d_w1 is not None else None), _ptr(d_z1 if d_w1 is not None else None), l2, _ptr(d_w1), _stream(d_out))
+          _ptr(ft if d_w1 is not None else None), _ptr(d_z1 if d_w1 is not None else None), l2, _ptr(d_w1), _ptr(sq_partial),
+          _stream(d_out))
     return d_weight, d_bias, dst
 
 
@@ -797,7 +805,7 @@ def sgd_scratch_bytes(count: int) -> int:
 
 def sgd_step(params: torch.Tensor, grads: torch.Tensor, momentum_buf: Optional[torch.Tensor], lr: float,
              momentum: float, weight_decay: float, max_norm: float, grad_scale: float, first_step: bool,
-             norm_out: Optional[torch.Tensor], scratch: torch.Tensor, ste=None) -> None:
+             norm_out: Optional[torch.Tensor], scratch: torch.Tensor, ste=None, ext=None) -> None:
     """ste = (partial scratch of ste_conv_backward(stages=1), chunks, fps, d_thr, d_weight): the deferred second stage
     runs inside the norm launch; d_thr / d_weight must be the first elements of `grads`."""
     params = _need(params, torch.float32, "flat params")
@@ -809,9 +817,11 @@ def sgd_step(params: torch.Tensor, grads: torch.Tensor, momentum_buf: Optional[t
         ste_args = (part.data_ptr(), int(chunks), int(fps), d_thr.data_ptr(), d_weight.data_ptr())
     else:
         ste_args = (None, 0, 0, None, None)
+    # ext = (partials, lo, hi): a producer's sums of squares for grads[lo:hi] (e.g. ftm_backward(sq_partial=...))
+    ext_args = (ext[0].data_ptr(), ext[0].numel(), int(ext[1]), int(ext[2])) if ext is not None else (None, 0, 0, 0)
     _call("nnue_sgd_step", params.data_ptr(), grads.data_ptr(), _ptr(momentum_buf), params.numel(), float(lr),
           float(momentum), float(weight_decay), float(max_norm), float(grad_scale), int(bool(first_step)),
-          _ptr(norm_out), scratch.data_ptr(), scratch.numel(), *ste_args, _stream(params))
+          _ptr(norm_out), scratch.data_ptr(), scratch.numel(), *ste_args, *ext_args, _stream(params))
 
 
 def adam_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,

@@ -192,6 +192,9 @@ class NnueTrainer:
         self.defer_ste = (not self.dp.collectives and optimizer == "sgd" and os.environ.get("NNUE_DEFER_STE", "1") != "0"
                           and self.fps * 28 <= 4096 and self.layout.names[:2] == ["visual_threshold", "conv.weight"])
         self.ste_chunks = lib.ste_conv_backward_chunks(B, self.fps, self.gh, self.gw)
+        # single rank + SGD: the FT weight-gradient tiles leave their sums of squares, so the clip norm does not read
+        # those rows of the flat gradient buffer again (268 MB at the 224x224 configuration)
+        self.sq_partial, self.sq_range = None, None
         self.fuse_l1 = (self.use_mfma and os.environ.get("NNUE_FUSE_L1", "1") != "0"
                         and lib.ftm_forward_l1_supported(B, self.F, self.P, self.L1, self.L2))
         self.steps_done = 0
@@ -211,6 +214,13 @@ class NnueTrainer:
         # tile family reading d_z1 out of the classifier's scratch) where that launch is used
         self.ride_dw1 = (self.use_mfma and self.merge_backward and os.environ.get("NNUE_FTM_RIDE_DW1", "1") != "0"
                          and lib.ftm_backward_cw_supported(B, self.F, self.P, self.L1, self.L2))
+        n_sq = lib.ftm_backward_sq_count(B, self.F, self.P, self.L1) if (self.use_mfma and self.merge_backward) else 0
+        if (n_sq > 0 and not self.dp.collectives and optimizer == "sgd" and os.environ.get("NNUE_NORM_PARTIALS", "1") != "0"):
+            off = self.layout.offsets[self.layout.names.index("input.weight")]
+            rows = min(self.F - 1, self.P)
+            if off % 4 == 0 and (rows * self.L1) % 4 == 0:
+                self.sq_partial = torch.empty((n_sq,), **f32)
+                self.sq_range = (off, off + rows * self.L1)
         self.d_z1 = None
         if self.ride_dw1:
             off = lib.classifier_train_dz1_offset(B, self.L1, self.L2, self.L3, self.C, True)
@@ -272,7 +282,7 @@ class NnueTrainer:
                 # weight gradient, value gradient and tail rows share one launch (independent work, all read d_ft)
                 lib.ftm_backward(self.d_ft, p["input.weight"], self.fm, d_weight=g["input.weight"], d_bias=g["input.bias"],
                                  dst=self.d_conv_out, ft=self.ft, d_z1=self.d_z1,
-                                 d_w1=g["classifier.classifier.0.weight"] if self.ride_dw1 else None)
+                                 d_w1=g["classifier.classifier.0.weight"] if self.ride_dw1 else None, sq_partial=self.sq_partial)
             elif self.use_mfma:
                 lib.ftm_backward_weight(self.d_ft, self.fm, d_weight=g["input.weight"], d_bias=g["input.bias"])
             elif self.use_bits:
@@ -316,7 +326,8 @@ class NnueTrainer:
             ste = ((self.ste_scratch, self.ste_chunks, self.fps, self.g["visual_threshold"], self.g["conv.weight"])
                    if self.defer_ste else None)
             lib.sgd_step(self.flat_params, self.flat_grads, self.flat_momentum, self.lr, self.momentum, self.weight_decay,
-                         self.max_grad_norm, scale, first, self.grad_norm, self.sgd_scratch, ste=ste)
+                         self.max_grad_norm, scale, first, self.grad_norm, self.sgd_scratch, ste=ste,
+                         ext=(self.sq_partial, *self.sq_range) if self.sq_partial is not None else None)
 
     def _optimizer_buffers(self):
         return [t for t in (self.flat_momentum, self.flat_exp_avg, self.flat_exp_avg_sq, self.adam_step_count) if t is not None]

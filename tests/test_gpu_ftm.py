@@ -264,3 +264,41 @@ def test_rider_is_refused_where_the_launch_is_split(hip):
     z = lambda *s: torch.zeros(*s, device=DEV)  # noqa: E731
     with pytest.raises(hip.NnueHipError):
         hip.ftm_backward(z(8, 1000), z(800, 1000), fm, ft=z(8, 1000), d_z1=z(8, 128), d_w1=z(128, 1000))
+
+
+@pytest.mark.parametrize("shape", [(512, 8, 11, 11, 800, 1024), (1024, 8, 11, 11, 800, 1024), (128, 64, 32, 32, 65536, 1024),
+                                   (37, 4, 8, 8, 300, 64)])
+def test_weight_gradient_tiles_leave_their_squared_norm(hip, shape):
+    """nnue_ftm_backward(sq_partial): the per-tile sums of squares add up to ||d_weight[:min(F-1, P)]||^2, outputs keep
+    their bits; nnue_sgd_step(ext=...) with them gives the norm / update of the plain call within float rounding."""
+    b, fps, gh, gw, f, l1 = shape
+    p = fps * gh * gw
+    n_sq = hip.ftm_backward_sq_count(b, f, p, l1)
+    assert n_sq > 0
+    gen = torch.Generator().manual_seed(b + f)
+    conv_out = torch.randn(b, fps, gh, gw, generator=gen).to(DEV)
+    thr = torch.full((fps,), 0.2).to(DEV)
+    weight = (torch.randn(f, l1, generator=gen) * 0.1).to(DEV)
+    d_out = (torch.randn(b, l1, generator=gen) / b).to(DEV)
+    fm = hip.ftm_binarize(conv_out, thr, f, l1)
+    ref_w, ref_b, ref_v = hip.ftm_backward(d_out, weight, fm)
+    sq = torch.full((n_sq,), float("nan"), device=DEV)
+    d_w, d_b, d_v = hip.ftm_backward(d_out, weight, fm, sq_partial=sq)
+    assert torch.equal(d_w, ref_w) and torch.equal(d_b, ref_b) and torch.equal(d_v, ref_v)
+    rows = min(f - 1, p)
+    want = float((d_w[:rows].double() ** 2).sum())
+    got = float(sq.double().sum())
+    assert abs(got - want) <= 1e-5 * max(want, 1e-30)
+    if f * l1 > 4_000_000:
+        return  # the optimizer part on the small tables only (keeps the test's memory small)
+    count = f * l1 + 1024
+    grads = torch.cat([d_w.reshape(-1), torch.randn(1024, generator=gen).to(DEV)])
+    params = torch.randn(count, generator=gen).to(DEV)
+    outs = []
+    for ext in (None, (sq, 0, rows * l1)):
+        pp, mom, norm = params.clone(), torch.zeros(count, device=DEV), torch.zeros((), device=DEV)
+        scratch = torch.empty((hip.sgd_scratch_bytes(count),), dtype=torch.uint8, device=DEV)
+        hip.sgd_step(pp, grads.clone(), mom, 0.05, 0.9, 1e-4, 0.5, 0.5, True, norm, scratch, ext=ext)
+        outs.append((pp, float(norm)))
+    assert abs(outs[0][1] - outs[1][1]) <= 1e-5 * outs[0][1]
+    assert_close_grad(outs[1][0], outs[0][0], "updated parameters", rtol=1e-5)
