@@ -64,9 +64,13 @@ __global__ __launch_bounds__(256) void conv_binarize_kernel(const float* __restr
                                                             uint8_t* __restrict__ bits, int* __restrict__ n,
                                                             float* __restrict__ sink, int H, int W, int fps, int stride,
                                                             int Gh, int Gw, int F, int slices) {
-  extern __shared__ float w_lds[];  // [fps][27] | thr [fps]
+  // weights transposed to [27][fpad] (fpad = fps rounded up to 8, pad columns zero): the eight channels of a register
+  // pass are two ds_read_b128 per patch term instead of eight ds_read_b32 -- the kernel was LDS-issue bound (1728 reads
+  // per thread at 64 channels); thr [fpad] behind them
+  extern __shared__ __attribute__((aligned(16))) float w_lds[];
   __shared__ int cnt_s[4], sink_s[4];
-  float* thr_lds = w_lds + fps * 27;
+  const int fpad = (fps + 7) & ~7;
+  float* thr_lds = w_lds + 27 * fpad;
   const int G = Gh * Gw;
   const int b = blockIdx.x;
   // the first position's patch is requested before the weights are staged: a launch starts with cold caches, and the
@@ -87,8 +91,11 @@ __global__ __launch_bounds__(256) void conv_binarize_kernel(const float* __restr
   };
   const int hw0 = blockIdx.y * blockDim.x + threadIdx.x;
   if (hw0 < G) load_patch(hw0);
-  for (int i = threadIdx.x; i < fps * 27; i += blockDim.x) w_lds[i] = w[i];
-  for (int i = threadIdx.x; i < fps; i += blockDim.x) thr_lds[i] = thr[i];
+  for (int i = threadIdx.x; i < 27 * fpad; i += blockDim.x) {
+    const int q = i / fpad, c = i - q * fpad;
+    w_lds[i] = c < fps ? w[c * 27 + q] : 0.0f;
+  }
+  for (int i = threadIdx.x; i < fpad; i += blockDim.x) thr_lds[i] = i < fps ? thr[i] : 0.0f;
   __syncthreads();
   int cnt = 0, snk = 0;
   for (int hw = hw0; hw < G; hw += blockDim.x * slices) {
@@ -97,13 +104,16 @@ __global__ __launch_bounds__(256) void conv_binarize_kernel(const float* __restr
       float acc[kConvChunk];
 #pragma unroll
       for (int u = 0; u < kConvChunk; ++u) acc[u] = 0.0f;
+      static_assert(kConvChunk == 8, "two float4 per patch term");
 #pragma unroll
-      for (int q = 0; q < 27; ++q)
-#pragma unroll
-        for (int u = 0; u < kConvChunk; ++u) {
-          const int c = (c0 + u < fps) ? c0 + u : fps - 1;  // clamp keeps the LDS read in range
-          acc[u] = fmaf(patch[q], w_lds[c * 27 + q], acc[u]);
-        }
+      for (int q = 0; q < 27; ++q) {
+        const float4 wa = *reinterpret_cast<const float4*>(&w_lds[q * fpad + c0]);
+        const float4 wb = *reinterpret_cast<const float4*>(&w_lds[q * fpad + c0 + 4]);
+        acc[0] = fmaf(patch[q], wa.x, acc[0]); acc[1] = fmaf(patch[q], wa.y, acc[1]);
+        acc[2] = fmaf(patch[q], wa.z, acc[2]); acc[3] = fmaf(patch[q], wa.w, acc[3]);
+        acc[4] = fmaf(patch[q], wb.x, acc[4]); acc[5] = fmaf(patch[q], wb.y, acc[5]);
+        acc[6] = fmaf(patch[q], wb.z, acc[6]); acc[7] = fmaf(patch[q], wb.w, acc[7]);
+      }
 #pragma unroll
       for (int u = 0; u < kConvChunk; ++u)
         if (c0 + u < fps) {
@@ -471,7 +481,7 @@ extern "C" int nnue_ftm_conv_binarize(const float* images, const float* weight, 
   NNUE_REQUIRE(images && weight && thr && conv_out && bits && n && sink, NNUE_E_ARG, "nnue_ftm_conv_binarize: null pointer");
   NNUE_REQUIRE(B > 0 && H > 0 && W > 0 && fps > 0 && stride > 0 && F > 0, NNUE_E_ARG,
                "nnue_ftm_conv_binarize: B=%d H=%d W=%d fps=%d stride=%d F=%d must be positive", B, H, W, fps, stride, F);
-  NNUE_REQUIRE(fps * 28 * 4 <= 64 * 1024, NNUE_E_SHAPE, "nnue_ftm_conv_binarize: fps=%d too large for the LDS weight tile", fps);
+  NNUE_REQUIRE(((fps + 7) & ~7) * 28 * 4 <= 64 * 1024, NNUE_E_SHAPE, "nnue_ftm_conv_binarize: fps=%d too large for the LDS weight tile", fps);
   const int Gh = (H - 1) / stride + 1, Gw = (W - 1) / stride + 1;
   const long long G = (long long)Gh * Gw;
   NNUE_REQUIRE(G * fps < (1ll << 30) && (long long)B * G * fps < (1ll << 40), NNUE_E_SHAPE, "nnue_ftm_conv_binarize: map too large");
@@ -483,7 +493,7 @@ extern "C" int nnue_ftm_conv_binarize(const float* images, const float* weight, 
   if (slices > (int)(G / threads)) slices = (int)(G / threads);
   slices = slices < 1 ? 1 : (slices > 16 ? 16 : slices);
   if (slices > 1) nnue_zero_counters(n, sink, B, s);  // a kernel, not a memset node (common.h)
-  hipLaunchKernelGGL(conv_binarize_kernel, dim3(B, slices), dim3(threads), fps * 28 * sizeof(float), s, images, weight, thr, conv_out, bits, n,
+  hipLaunchKernelGGL(conv_binarize_kernel, dim3(B, slices), dim3(threads), (size_t)(((fps + 7) & ~7) * 28) * sizeof(float), s, images, weight, thr, conv_out, bits, n,
                      sink, H, W, fps, stride, Gh, Gw, F, slices);
   return nnue_launch_status("nnue_ftm_conv_binarize");
 }
