@@ -134,16 +134,16 @@ __global__ __launch_bounds__(256) void sqnorm_stage1(const float* __restrict__ g
 // The norm launch with the second stage of a deferred nnue_ste_conv_backward riding in it (feature_kernels.hip,
 // ste_conv_backward_stage2: one wave per (channel, term), lanes stride over the output's contiguous run of partials,
 // the same sums in the same order).  Workgroups [0, s2_blocks) write d_thr / d_weight -- the first `skip` elements of
-// g -- and leave the squares of their four outputs in partial[kNormBlocks + block]; the others are the plain norm
+// g -- and leave the squares of their four outputs in partial[nb + block] (nb = plain norm workgroups); the others are the plain norm
 // workgroups over g[skip:].
 __global__ __launch_bounds__(256) void sqnorm_stage1_ste(const float* __restrict__ g, int64_t count, float scale,
                                                          float* __restrict__ partial, const float* __restrict__ ste_partial,
                                                          int chunks, int fps, float* __restrict__ d_thr,
                                                          float* __restrict__ d_weight, int s2_blocks, int64_t skip, int64_t lo,
-                                                         int64_t hi) {
+                                                         int64_t hi, int nb) {
   __shared__ float red[4];
   if ((int)blockIdx.x >= s2_blocks) {
-    const float v = sqnorm_block_partial_skip(g + skip, count - skip, scale, red, (int)blockIdx.x - s2_blocks, kNormBlocks,
+    const float v = sqnorm_block_partial_skip(g + skip, count - skip, scale, red, (int)blockIdx.x - s2_blocks, nb,
                                               lo > skip ? lo - skip : 0, hi > skip ? hi - skip : 0);
     if (threadIdx.x == 0) partial[blockIdx.x - s2_blocks] = v;
     return;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void sqnorm_stage1_ste(const float* __restrict
   }
   if (lane == 0) red[threadIdx.x >> 6] = sq;
   __syncthreads();
-  if (threadIdx.x == 0) partial[kNormBlocks + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x == 0) partial[nb + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // Every block re-derives the norm from the kNormBlocks partials (4 KiB, L2-resident) in the same
@@ -318,7 +318,11 @@ extern "C" int nnue_sgd_step(float* params, float* grads, float* momentum_buf, i
                (long long)scratch_bytes, (long long)nnue_sgd_scratch(count));
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* partial = static_cast<float*>(scratch);
-  int nparts = kNormBlocks;
+  // norm workgroups: 16 floats per thread while that still leaves fewer than kNormBlocks (a small model's apply kernel
+  // then re-derives the norm from a few hundred partials instead of 1024)
+  int nb = (int)((count + 4095) / 4096);
+  nb = nb < 64 ? 64 : (nb > kNormBlocks ? kNormBlocks : nb);
+  int nparts = nb;
   if (ext_partial) {
     NNUE_REQUIRE(ext_count > 0 && ext_count <= 65536 && ext_lo >= 0 && ext_lo < ext_hi && ext_hi <= count && ext_lo % 4 == 0 && ext_hi % 4 == 0,
                  NNUE_E_ARG, "nnue_sgd_step: producer partials need 0 < count <= 65536 and a range [lo, hi) of multiples of 4 inside grads");
@@ -340,11 +344,11 @@ extern "C" int nnue_sgd_step(float* params, float* grads, float* momentum_buf, i
     const int s2_blocks = (ste_fps * 28 + 3) / 4;
     // padding between / after the two outputs is never written by the sums: it enters neither the norm nor is it read
     // before the update multiplies it -- keep it zero (the flat gradient buffer's padding is zero-initialised)
-    hipLaunchKernelGGL(sqnorm_stage1_ste, dim3(kNormBlocks + s2_blocks), dim3(256), 0, s, grads, count, grad_scale, partial, ste_partial,
-                       ste_chunks, ste_fps, ste_d_thr, ste_d_weight, s2_blocks, skip, ext_lo, ext_hi);
-    nparts = kNormBlocks + s2_blocks;
+    hipLaunchKernelGGL(sqnorm_stage1_ste, dim3(nb + s2_blocks), dim3(256), 0, s, grads, count, grad_scale, partial, ste_partial,
+                       ste_chunks, ste_fps, ste_d_thr, ste_d_weight, s2_blocks, skip, ext_lo, ext_hi, nb);
+    nparts = nb + s2_blocks;
   } else if (max_norm > 0.0f || norm_out) {
-    hipLaunchKernelGGL(sqnorm_stage1, dim3(kNormBlocks), dim3(256), 0, s, grads, count, grad_scale, partial, ext_lo, ext_hi);
+    hipLaunchKernelGGL(sqnorm_stage1, dim3(nb), dim3(256), 0, s, grads, count, grad_scale, partial, ext_lo, ext_hi);
   }
   int blocks = (int)((count + 1023) / 1024);
   if (blocks > 2048) blocks = 2048;
