@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """NNUE training throughput on MI355X  (metric: BASELINE.json -- images/sec of the full training step).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3|c4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3|c4]      (N > 1: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
@@ -58,7 +58,60 @@ def parse():
     ap.add_argument("--no-gather-compare", action="store_true",
                     help="skip the second pass with the LDS-staged gather kernels (NNUE_FT_PATH=bits) and its HBM-roofline object")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="rehearse the self-launch path without a GPU: the ranks rendezvous over gloo, all-reduce a small flat "
+                         "buffer through the trainer's DataParallel plumbing and rank 0 prints the JSON line (tests/test_bench_launcher.py)")
     return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks ourselves as a child
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same flags>` (one rank per GPU over RCCL), relay rank 0's
+    single JSON line and return the children's exit code.  Runs before this process touches the GPU (nothing here calls
+    into HIP), so there is no exec from a process that has initialised the device."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line is not None:
+        print(line, flush=True)
+    elif proc.returncode == 0:
+        print("bench.py: the ranks exited 0 without a result line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
+def launcher_selftest(args, world, rank):
+    """CPU rehearsal of the multi-rank plumbing (no kernels, no timing claim): gloo rendezvous, the trainer's DataParallel
+    all-reduce on a flat buffer, max-over-ranks reduction, one JSON line from rank 0."""
+    sys.path.insert(0, str(ROOT / "nnue-vision_amd"))
+    from nnue_hip.trainer import DataParallel
+    dist.init_process_group("gloo")
+    dp = DataParallel()
+    flat = torch.full((1024,), float(rank + 1))
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dp.allreduce_sum(flat)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher selftest (no kernels)", "value": 0.0, "unit": "images/sec", "n_gpus": args.gpus,
+                          "n_ranks": dist.get_world_size(), "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(float(t.item()) * 1e3 / max(1, args.steps), 4), "selftest": True,
+                          "allreduce_ok": bool(dp.world == world)}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def cpu_baseline(cfg, budget_s):
@@ -95,6 +148,10 @@ def cpu_baseline(cfg, budget_s):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    if args.launcher_selftest:
+        return launcher_selftest(args, int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")))
     # stdout carries exactly ONE line (the JSON): libraries that chat on fd 1 (RCCL prints a version banner
     # at communicator creation) are sent to stderr until the result is ready
     sys.stdout.flush()
@@ -104,8 +161,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
@@ -325,6 +380,7 @@ def main():
             "value": round(B * world * args.steps / elapsed, 1),
             "unit": "images/sec",
             "n_gpus": world,
+            "n_ranks": dist.get_world_size() if dist.is_initialized() else 1,  # as RCCL saw it
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
