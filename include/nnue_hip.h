@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 17
+#define NNUE_HIP_ABI_VERSION 18
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -61,6 +61,21 @@ const char* nnue_hip_last_error(void);
  * (ci, kh, kw) in that order, so results do not depend on the launch shape. */
 int nnue_conv3x3_forward(const float* images, const float* weight, float* conv_out,
                          int B, int H, int W, int fps, int stride, nnue_stream_t stream);
+
+/* Gradient of that conv w.r.t. its input (autograd of nnue.py:640; the training step never needs it -- offered
+ * so that NNUE.forward's autograd node differentiates w.r.t. the pixels without a stock op):
+ *   d_images[b,ci,y,x] = sum_{c,kh,kw : y = oh*stride+kh-1, x = ow*stride+kw-1} d_conv_out[b,c,oh,ow] * weight[c,ci,kh,kw]
+ * one fixed-order fmaf chain per pixel and channel. */
+int nnue_conv3x3_backward_input(const float* d_conv_out, const float* weight, int B, int H, int W, int fps,
+                                int stride, float* d_images, nnue_stream_t stream);
+
+/* The value half of NNUE._to_sparse_features (nnue.py:601-606, :628-633): the values are the map's own entries at the
+ * active ids:  val[b,i] = map[b, idx[b,i]]  (idx >= 0; 0 for the -1 padding);  map [B,P], idx int64 [B,M]. */
+int nnue_sparse_values(const float* map, const int64_t* idx, int B, int P, int M, float* val, nnue_stream_t stream);
+/* ... and its autograd (CopySlices / IndexBackward of nnue.py:628-633): the values stay attached to the map,
+ *   d_map[b,idx[b,i]] = d_val[b,i], every other element 0 (ids of a sample are distinct). */
+int nnue_sparse_values_backward(const float* d_val, const int64_t* idx, int B, int P, int M, float* d_map,
+                                nnue_stream_t stream);
 
 /* StraightThroughBinary.forward + NNUE._to_sparse_features  (nnue.py:19-25, :590-635)
  * without the data-dependent width: per sample, ascending flat ids p = c*Gh*Gw + h*Gw + w

@@ -13,8 +13,9 @@ CSRC = Path(__file__).resolve().parent
 ROOT = CSRC.parent.parent
 OUT = CSRC.parent / "nnue_hip" / "libnnue_hip.so"
 SOURCES = ["abi.cpp", "ft_kernels.hip", "ftb_kernels.hip", "ftm_kernels.hip", "feature_kernels.hip", "classifier_kernels.hip", "optim_kernels.hip", "input_kernels.hip", "engine_kernels.hip"]
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result",
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result",
          "-fno-gpu-rdc", "-x", "hip", f"-I{ROOT / 'include'}", f"-I{CSRC}"]
+OBJ = CSRC / "build"  # per-source objects (git-ignored): only changed sources are recompiled, in parallel
 
 
 def stale() -> bool:
@@ -28,8 +29,24 @@ def stale() -> bool:
 def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not stale():
         return OUT
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, *FLAGS, *[str(CSRC / s) for s in SOURCES], "-o", str(OUT)]
+    OBJ.mkdir(exist_ok=True)
+    shared = [CSRC / "common.h", ROOT / "include" / "nnue_hip.h", Path(__file__)]
+    newest_shared = max(d.stat().st_mtime for d in shared)
+
+    def compile_one(src: str) -> Path:
+        obj = OBJ / (src.rsplit(".", 1)[0] + ".o")
+        if force or not obj.exists() or obj.stat().st_mtime < max((CSRC / src).stat().st_mtime, newest_shared):
+            cmd = [hipcc, *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-fno-gpu-rdc", "-shared", "-fPIC", *[str(o) for o in objs], "-o", str(OUT)]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

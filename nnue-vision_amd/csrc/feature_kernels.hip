@@ -458,6 +458,72 @@ int64_t ste_mfma_blocks(int64_t positions) {
   return blocks > 0 ? blocks : 1;
 }
 
+// ------------------------------------------------------------------ conv backward w.r.t. the pixels
+// d_images[b][ci][y][x] = sum_{c,kh,kw} d_conv_out[b][c][oh][ow] * w[c][ci][kh][kw] over the taps with
+// y = oh*stride + kh - 1, x = ow*stride + kw - 1 (transposed conv; the training loop never needs it, NNUE.forward's
+// autograd node offers it for callers that differentiate w.r.t. the input).  Thread = one pixel, all three input
+// channels; fixed order (kh, kw, c): reproducible.
+__global__ __launch_bounds__(256) void conv3x3_backward_input_kernel(const float* __restrict__ d_out, const float* __restrict__ w,
+                                                                     float* __restrict__ d_img, int B, int H, int W, int fps,
+                                                                     int stride, int Gh, int Gw) {
+  extern __shared__ float w_lds[];  // [fps][27]
+  for (int i = threadIdx.x; i < fps * 27; i += blockDim.x) w_lds[i] = w[i];
+  __syncthreads();
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)B * H * W) return;
+  const int b = (int)(t / ((long long)H * W));
+  const int yx = (int)(t - (long long)b * H * W);
+  const int y = yx / W, x = yx - y * W;
+  const int G = Gh * Gw;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int ny = y + 1 - kh;
+    if (ny < 0 || ny % stride) continue;
+    const int oh = ny / stride;
+    if (oh >= Gh) continue;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int nx = x + 1 - kw;
+      if (nx < 0 || nx % stride) continue;
+      const int ow = nx / stride;
+      if (ow >= Gw) continue;
+      const float* __restrict__ d = d_out + (size_t)b * fps * G + oh * Gw + ow;
+      const int q = kh * 3 + kw;
+      for (int c = 0; c < fps; ++c) {
+        const float g = d[(size_t)c * G];
+        a0 = fmaf(g, w_lds[c * 27 + q], a0);
+        a1 = fmaf(g, w_lds[c * 27 + 9 + q], a1);
+        a2 = fmaf(g, w_lds[c * 27 + 18 + q], a2);
+      }
+    }
+  }
+  float* __restrict__ o = d_img + (size_t)b * 3 * H * W + yx;
+  o[0] = a0;
+  o[(size_t)H * W] = a1;
+  o[(size_t)2 * H * W] = a2;
+}
+
+// ------------------------------------------------------------------ _to_sparse_features: values and their gradient
+// val[b][i] = map[b][idx[b][i]] for idx >= 0, else 0 (nnue.py:628-633: the values stay attached to the map)
+__global__ __launch_bounds__(256) void sparse_values_gather_kernel(const float* __restrict__ map, const int64_t* __restrict__ idx,
+                                                                   long long total, int P, int M, float* __restrict__ val) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const long long b = t / M;
+  const int64_t p = idx[t];
+  val[t] = (p >= 0 && p < P) ? map[b * P + p] : 0.0f;
+}
+// d_map[b][idx[b][i]] = d_val[b][i]; ids of one sample are distinct (they come from nonzero()), so plain stores
+__global__ __launch_bounds__(256) void sparse_values_scatter_kernel(const float* __restrict__ d_val, const int64_t* __restrict__ idx,
+                                                                    long long total, int P, int M, float* __restrict__ d_map) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const long long b = t / M;
+  const int64_t p = idx[t];
+  if (p >= 0 && p < P) d_map[b * P + p] = d_val[t];
+}
+
 }  // namespace
 
 // =============================================================================== C ABI
@@ -573,4 +639,38 @@ extern "C" int nnue_ste_conv_backward(const float* images, const float* conv_out
   if (stages & 2)
     hipLaunchKernelGGL(ste_conv_backward_stage2, dim3((fps * 28 + 3) / 4), dim3(256), 0, s, partial, chunks, fps, d_thr, d_weight);
   return nnue_launch_status("nnue_ste_conv_backward");
+}
+
+extern "C" int nnue_conv3x3_backward_input(const float* d_conv_out, const float* weight, int B, int H, int W, int fps, int stride,
+                                           float* d_images, nnue_stream_t stream) {
+  NNUE_REQUIRE(d_conv_out && weight && d_images, NNUE_E_ARG, "nnue_conv3x3_backward_input: null pointer");
+  NNUE_REQUIRE(B > 0 && H > 0 && W > 0 && fps > 0 && stride > 0, NNUE_E_ARG,
+               "nnue_conv3x3_backward_input: B=%d H=%d W=%d fps=%d stride=%d must be positive", B, H, W, fps, stride);
+  NNUE_REQUIRE(fps * 27 * 4 <= 64 * 1024, NNUE_E_SHAPE, "nnue_conv3x3_backward_input: fps=%d too large for the LDS weight tile", fps);
+  const int Gh = (H - 1) / stride + 1, Gw = (W - 1) / stride + 1;
+  const long long total = (long long)B * H * W;
+  NNUE_REQUIRE(total < (1ll << 31) * 256, NNUE_E_SHAPE, "nnue_conv3x3_backward_input: too many pixels");
+  hipLaunchKernelGGL(conv3x3_backward_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), fps * 27 * sizeof(float),
+                     static_cast<hipStream_t>(stream), d_conv_out, weight, d_images, B, H, W, fps, stride, Gh, Gw);
+  return nnue_launch_status("nnue_conv3x3_backward_input");
+}
+
+extern "C" int nnue_sparse_values(const float* map, const int64_t* idx, int B, int P, int M, float* val, nnue_stream_t stream) {
+  NNUE_REQUIRE(map && idx && val, NNUE_E_ARG, "nnue_sparse_values: null pointer");
+  NNUE_REQUIRE(B > 0 && P > 0 && M > 0, NNUE_E_ARG, "nnue_sparse_values: B=%d P=%d M=%d must be positive", B, P, M);
+  const long long total = (long long)B * M;
+  hipLaunchKernelGGL(sparse_values_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), map,
+                     idx, total, P, M, val);
+  return nnue_launch_status("nnue_sparse_values");
+}
+
+extern "C" int nnue_sparse_values_backward(const float* d_val, const int64_t* idx, int B, int P, int M, float* d_map,
+                                           nnue_stream_t stream) {
+  NNUE_REQUIRE(d_val && idx && d_map, NNUE_E_ARG, "nnue_sparse_values_backward: null pointer");
+  NNUE_REQUIRE(B > 0 && P > 0 && M > 0, NNUE_E_ARG, "nnue_sparse_values_backward: B=%d P=%d M=%d must be positive", B, P, M);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  nnue_zero_floats(d_map, (size_t)B * P, s);
+  const long long total = (long long)B * M;
+  hipLaunchKernelGGL(sparse_values_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_val, idx, total, P, M, d_map);
+  return nnue_launch_status("nnue_sparse_values_backward");
 }

@@ -178,17 +178,17 @@ class NNUE(nn.Module):
     def _to_sparse_features(self, binary_features: torch.Tensor):
         """Reference-format sparse view of a {0,1} map: (idx int64 [B,M] padded -1, val float32 [B,M]),
         M = max(max active, 1) (nnue.py:590-635).  The width is data dependent, so this call reads one
-        integer back from the device; NNUE.forward itself never calls it.  Not differentiable."""
+        integer back from the device; NNUE.forward itself never calls it.  As in the reference the ids carry
+        no gradient and the values stay attached to the map (nnue.py:628-633): gradients flow back to
+        ``binary_features`` at the active positions."""
+        bsz = binary_features.shape[0]
+        flat = binary_features.reshape(bsz, -1).to(torch.float32)
         with torch.no_grad():
-            bsz = binary_features.shape[0]
-            flat = binary_features.reshape(bsz, 1, 1, -1).to(torch.float32)
             half = torch.full((1,), 0.5, dtype=torch.float32, device=flat.device)
-            act = _lib.binarize_features(flat, half, max(int(flat.shape[-1]), 1))
+            act = _lib.binarize_features(flat.detach().reshape(bsz, 1, 1, -1), half, max(int(flat.shape[-1]), 1))
             width = max(int(act.n.max().item()), 1)
             idx, _ = _lib.act_to_padded(act, width)
-            # the reference returns the map's own values at the active ids (1.0 for a binary map)
-            vals = binary_features.reshape(bsz, -1).to(torch.float32).gather(1, idx.clamp(min=0))
-            return idx, torch.where(idx >= 0, vals, torch.zeros_like(vals))
+        return idx, _ops.SparseValuesFn.apply(flat, idx)
 
     # ---- export ------------------------------------------------------------------------------
     def _clip_weights(self):

@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -25,6 +25,9 @@ SIGNATURES = {
     "nnue_hip_abi_version": (_c_int, []),
     "nnue_hip_last_error": (ctypes.c_char_p, []),
     "nnue_conv3x3_forward": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    "nnue_conv3x3_backward_input": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p]),
+    "nnue_sparse_values": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p]),
+    "nnue_sparse_values_backward": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p]),
     "nnue_binarize_features": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                                         _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_p]),
     "nnue_act_to_padded": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
@@ -229,6 +232,38 @@ def conv3x3_forward(images: torch.Tensor, weight: torch.Tensor, stride: int,
     _call("nnue_conv3x3_forward", images.data_ptr(), weight.data_ptr(), out.data_ptr(), b, h, w, fps, stride,
           _stream(images))
     return out
+
+
+def conv3x3_backward_input(d_conv_out: torch.Tensor, weight: torch.Tensor, image_shape, stride: int) -> torch.Tensor:
+    """d(images) of the 3x3 / pad 1 conv: [B,3,H,W] from d_conv_out [B,fps,Gh,Gw]."""
+    b, _, h, w = image_shape
+    fps = weight.shape[0]
+    gh, gw = conv_out_hw(h, w, stride)
+    d_conv_out = _need(d_conv_out, torch.float32, "d_conv_out", (b, fps, gh, gw))
+    weight = _need(weight, torch.float32, "conv weight", (fps, 3, 3, 3))
+    d_images = torch.empty((b, 3, h, w), dtype=torch.float32, device=d_conv_out.device)
+    _call("nnue_conv3x3_backward_input", d_conv_out.data_ptr(), weight.data_ptr(), b, h, w, fps, int(stride), d_images.data_ptr(),
+          _stream(d_conv_out))
+    return d_images
+
+
+def sparse_values(flat_map: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """val[b,i] = map[b, idx[b,i]] (0 where idx < 0); map float32 [B,P], idx int64 [B,M]."""
+    flat_map = _need(flat_map, torch.float32, "feature map")
+    idx = _need(idx, torch.int64, "feature indices")
+    b, p = flat_map.shape
+    val = torch.empty(idx.shape, dtype=torch.float32, device=flat_map.device)
+    _call("nnue_sparse_values", flat_map.data_ptr(), idx.data_ptr(), b, p, idx.shape[1], val.data_ptr(), _stream(flat_map))
+    return val
+
+
+def sparse_values_backward(d_val: torch.Tensor, idx: torch.Tensor, positions: int) -> torch.Tensor:
+    d_val = _need(d_val, torch.float32, "d_val")
+    idx = _need(idx, torch.int64, "feature indices", tuple(d_val.shape))
+    b, m = idx.shape
+    d_map = torch.empty((b, positions), dtype=torch.float32, device=d_val.device)
+    _call("nnue_sparse_values_backward", d_val.data_ptr(), idx.data_ptr(), b, positions, m, d_map.data_ptr(), _stream(d_val))
+    return d_map
 
 
 def binarize_features(conv_out: torch.Tensor, thr: torch.Tensor, num_rows: int,

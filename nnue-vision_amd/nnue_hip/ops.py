@@ -1,7 +1,8 @@
 """autograd bridges between the nn.Module surface (nnue.py) and the HIP kernels.
 
-Three nodes, each a hand-written forward/backward pair over the C ABI:
+Four nodes, each a hand-written forward/backward pair over the C ABI:
 
+* ``SparseValuesFn``        -- the values returned by NNUE._to_sparse_features, attached to the map (nnue.py:628-633)
 * ``FeatureTransformerFn``  -- FeatureTransformer.forward called stand-alone (nnue.py:686-710)
 * ``ClassifierFn``          -- SimpleClassifier.forward called stand-alone (nnue.py:736-738)
 * ``NnueFn``                -- the whole NNUE.forward (nnue.py:637-671) as ONE node: conv, binarise +
@@ -55,6 +56,21 @@ class ClassifierFn(torch.autograd.Function):
         return (d_x, *g, None, None)
 
 
+class SparseValuesFn(torch.autograd.Function):
+    """The differentiable half of NNUE._to_sparse_features (nnue.py:628-633): val = map[idx], gradient scattered back."""
+
+    @staticmethod
+    def forward(ctx, flat_map, idx):
+        ctx.positions = flat_map.shape[1]
+        ctx.save_for_backward(idx)
+        return lib.sparse_values(flat_map.contiguous(), idx)
+
+    @staticmethod
+    def backward(ctx, d_val):
+        (idx,) = ctx.saved_tensors
+        return lib.sparse_values_backward(d_val.contiguous(), idx, ctx.positions), None
+
+
 class NnueFn(torch.autograd.Function):
     """images -> logits.  Inputs: images, threshold [fps], conv weight, FT weight/bias, 3x (weight, bias)."""
 
@@ -103,7 +119,6 @@ class NnueFn(torch.autograd.Function):
             if need[1] or need[2]:
                 d_thr, d_conv_w = lib.ste_conv_backward(images, conv_out, thr, d_conv_out, ctx.stride)
                 d_thr = d_thr.view_as(thr)
-            if need[0]:
-                # gradient to the pixels: never needed by the training loop; stock transposed conv
-                d_images = torch.nn.grad.conv2d_input(images.shape, conv_w, d_conv_out, stride=ctx.stride, padding=1)
+            if need[0]:  # gradient to the pixels: never needed by the training loop
+                d_images = lib.conv3x3_backward_input(d_conv_out.contiguous(), conv_w, images.shape, ctx.stride)
         return (d_images, d_thr, d_conv_w, d_ftw, d_ftb, *g_cls, None, None)

@@ -130,7 +130,7 @@ def test_reference_structural_checks():
 
 def test_density_extremes_and_pixel_gradient():
     """Thresholds of -1e6 / +1e6 (everything / nothing active, reference tests/test_model.py:347-362) and
-    a gradient request for the pixels (falls back to a stock transposed conv)."""
+    a gradient request for the pixels (nnue_conv3x3_backward_input)."""
     torch.manual_seed(1)
     cfg = dict(grid=10, fps=8, l1=64, l2=32, l3=8, classes=10, input_size=32)
     model = build(cfg)
@@ -164,6 +164,59 @@ def test_density_extremes_and_pixel_gradient():
             assert not bool(x.grad.any())
         else:
             assert_close_grad(x.grad, xi.grad, f"d_images thr={thr}")
+
+
+@pytest.mark.parametrize("name", ("tiny4x4", "c1arch", "tiny96"))
+def test_composed_public_pieces_carry_the_reference_gradients(name):
+    """The reference's forward spelled out with the public pieces (nnue.py:640-669): conv -> binary_activation_ste ->
+    _to_sparse_features -> self.input -> pairwise -> self.classifier.  The values returned by _to_sparse_features stay
+    attached to the map (nnue.py:628-633), so conv weight and threshold receive the golden gradients this way too."""
+    cfg, params, grads, data = golden_model(name)
+    model = build(cfg, params)
+    x = F.conv2d(data["images"].to(DEV), model.conv.weight, stride=model.conv.stride, padding=1)
+    bits = nnue.binary_activation_ste(x, model.visual_threshold.view(1, -1, 1, 1))
+    idx, val = model._to_sparse_features(bits)
+    assert torch.equal(idx.cpu(), data["idx"]) and torch.equal(val.detach().cpu(), data["val"])
+    assert val.requires_grad and not idx.requires_grad
+    ft = model.input(idx, val)
+    half = cfg["l1"] // 2
+    logits = model.classifier(torch.cat([ft[:, :half] * ft[:, half:], ft[:, :half]], dim=1))
+    F.cross_entropy(logits, data["labels"].to(DEV).long()).backward()
+    assert_close_logits(logits, data["logits"], "logits")
+    for k, p in model.named_parameters():
+        if k != "nnue2score":
+            assert_close_grad(p.grad, grads[k], k)
+
+
+def test_sparse_values_follow_the_loop_form():
+    """_to_sparse_features on a map with non-binary entries: values are the map's own entries (nnue.py:601-606) and the
+    gradient lands on exactly those positions."""
+    gen = torch.Generator().manual_seed(5)
+    m = torch.rand(5, 3, 4, 6, generator=gen)
+    m[3] = 0.0  # a sample with nothing active
+    model = nnue.NNUE(nnue.GridFeatureSet(4, 3), 8, 4, 4, num_classes=2, input_size=8).to(DEV)
+    a = m.clone().requires_grad_(True)
+    ref_idx, ref_val = orc.to_sparse_features_loop(a)
+    w = torch.randn(ref_val.shape, generator=gen)
+    (ref_val * w).sum().backward()
+    b = m.to(DEV).requires_grad_(True)
+    idx, val = model._to_sparse_features(b)
+    assert torch.equal(idx.cpu(), ref_idx) and torch.equal(val.detach().cpu(), ref_val.detach())
+    (val * w.to(DEV)).sum().backward()
+    assert torch.equal(b.grad.cpu(), a.grad)
+
+
+@pytest.mark.parametrize("shape", ((2, 10, 10, 1, 5), (3, 33, 41, 3, 8), (1, 96, 96, 7, 16)))
+def test_pixel_gradient_kernel(shape):
+    from nnue_hip import lib
+    b, h, w, stride, fps = shape
+    gen = torch.Generator().manual_seed(b + h)
+    wt = torch.randn(fps, 3, 3, 3, generator=gen)
+    gh, gw = lib.conv_out_hw(h, w, stride)
+    d = torch.randn(b, fps, gh, gw, generator=gen)
+    ref = torch.nn.grad.conv2d_input((b, 3, h, w), wt.double(), d.double(), stride=stride, padding=1)
+    got = lib.conv3x3_backward_input(d.to(DEV), wt.to(DEV), (b, 3, h, w), stride)
+    assert_close_grad(got, ref, "d_images", rtol=1e-5)
 
 
 def test_serialize_from_gpu_model(tmp_path):
