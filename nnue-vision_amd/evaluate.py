@@ -55,6 +55,15 @@ def _host_confusion(outputs: torch.Tensor, targets: torch.Tensor) -> np.ndarray:
     return np.bincount(truth * k + pred, minlength=k * k).reshape(k, k)
 
 
+def _checked(confusion: np.ndarray, samples: int) -> np.ndarray:
+    """The HIP confusion kernel skips a sample whose label is outside [0, K): the matrix then holds fewer samples than
+    were scored.  sklearn would count such a sample and F.cross_entropy would raise -- so a corrupt label tensor is an
+    error here, found with the read-back the caller makes anyway (no extra launch or synchronisation)."""
+    if int(confusion.sum()) != samples:
+        raise ValueError(f"{samples - int(confusion.sum())} of {samples} labels lie outside [0, {confusion.shape[0]})")
+    return confusion
+
+
 def compute_metrics(outputs: torch.Tensor, targets: torch.Tensor) -> Dict[str, float]:
     """Same contract as the reference (evaluate.py:23-59).  GPU tensors are scored by the HIP kernel."""
     if outputs.is_cuda:
@@ -63,7 +72,8 @@ def compute_metrics(outputs: torch.Tensor, targets: torch.Tensor) -> Dict[str, f
             logits = logits.reshape(-1, 1)
         labels = targets.detach().reshape(-1)
         labels = (labels > 0.5).to(torch.int64) if logits.shape[1] == 1 else labels.to(torch.int64)
-        return metrics_from_confusion(_lib.confusion_accumulate(logits.contiguous(), labels.to(logits.device)).cpu().numpy())
+        conf = _lib.confusion_accumulate(logits.contiguous(), labels.to(logits.device)).cpu().numpy()
+        return metrics_from_confusion(_checked(conf, int(logits.shape[0])))
     return metrics_from_confusion(_host_confusion(outputs, targets))
 
 
@@ -83,7 +93,9 @@ def evaluate_model(model: torch.nn.Module, loader, loss_fn=None, device: Optiona
         return _evaluate_nnue_graph(model, loader, device)
     confusion = None
     losses = []
+    seen = 0
     for images, labels in loader:
+        seen += int(labels.shape[0])
         images = images.to(device, non_blocking=True)
         labels = labels.to(device, non_blocking=True).long()
         logits = model(images).float().contiguous()
@@ -95,13 +107,14 @@ def evaluate_model(model: torch.nn.Module, loader, loss_fn=None, device: Optiona
     if not losses:
         raise ValueError("evaluate_model: empty loader")
     total = torch.stack(losses).double().sum().item()  # the single synchronisation
-    return total / len(losses), metrics_from_confusion(confusion.cpu().numpy())
+    return total / len(losses), metrics_from_confusion(_checked(confusion.cpu().numpy(), seen))
 
 
 def _evaluate_nnue_graph(model, loader, device) -> Tuple[float, Dict[str, float]]:
     from nnue_hip.eval_plan import plan_for
-    plans, batches = [], 0
+    plans, batches, seen = [], 0, 0
     for images, labels in loader:
+        seen += int(labels.shape[0])
         if images.dim() != 4 or images.shape[1] != 3:
             raise ValueError(f"images: expected [B,3,H,W], got {tuple(images.shape)}")
         plan = plan_for(model, int(images.shape[0]), (int(images.shape[2]), int(images.shape[3])))
@@ -114,7 +127,8 @@ def _evaluate_nnue_graph(model, loader, device) -> Tuple[float, Dict[str, float]
         raise ValueError("evaluate_model: empty loader")
     total = sum(p.loss_sum for p in plans)      # per-batch means, summed in float64 on the device
     confusion = sum(p.confusion for p in plans)
-    return float(total.item()) / batches, metrics_from_confusion(confusion.cpu().numpy())  # the single synchronisation
+    mean_loss = float(total.item()) / batches  # the single synchronisation
+    return mean_loss, metrics_from_confusion(_checked(confusion.cpu().numpy(), seen))
 
 
 def evaluate_compiled_model(model: torch.nn.Module, loader, model_type: str) -> Dict[str, float]:

@@ -121,7 +121,7 @@ class NnueTrainer:
         if not p0.is_cuda:
             raise lib.NnueHipError("NnueTrainer needs the model on the GPU (no CPU fallback)")
         self.model, self.dev = model, p0.device
-        self.lr, self.momentum, self.weight_decay, self.max_grad_norm = lr, momentum, weight_decay, max_grad_norm
+        self._hyper = dict(lr=lr, momentum=momentum, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
         if optimizer not in ("sgd", "adam"):
             raise ValueError(f"optimizer must be 'sgd' or 'adam', got {optimizer!r}")
         self.optimizer, self.betas, self.eps = optimizer, betas, eps
@@ -201,6 +201,7 @@ class NnueTrainer:
         self.use_graph = use_graph
         self._g_local, self._g_update = {}, None
         self._plan_local = self._plan_seg = self._plan_update_first = self._plan_update = None
+        self._plan_slot = 0
         self._side = torch.cuda.Stream(device=self.dev) if use_graph else None
         self._s1 = torch.cuda.Stream(device=self.dev) if use_graph else None
         self._s2 = torch.cuda.Stream(device=self.dev) if use_graph else None
@@ -225,6 +226,30 @@ class NnueTrainer:
         if self.ride_dw1:
             off = lib.classifier_train_dz1_offset(B, self.L1, self.L2, self.L3, self.C, True)
             self.d_z1 = self.cls_scratch[off:off + B * self.L2 * 4].view(torch.float32).view(B, self.L2)
+
+    # ------------------------------------------------------------------ hyper-parameters
+    # The recorded update plan (and every graph captured from it) carries lr, momentum, weight decay and the clip norm
+    # as constants, so changing one re-records the update plan and drops the graphs that contain it; the local
+    # (forward/backward) plan is untouched.  ``trainer.lr = x`` and ``trainer.set_lr(x)`` are the same thing.
+    def _set_hyper(self, key: str, value: float) -> None:
+        if self._hyper[key] == value:
+            return
+        if key == "momentum" and self.optimizer == "sgd" and bool(value) != (self.flat_momentum is not None):
+            raise ValueError("momentum cannot be switched on or off after construction (the buffer layout is fixed)")
+        self._hyper[key] = value
+        self._plan_update_first = self._plan_update = None
+        self._g_update = None
+        for key_ in [k for k in self._g_local if k[1] == "full"]:
+            del self._g_local[key_]
+
+    lr = property(lambda self: self._hyper["lr"], lambda self, v: self._set_hyper("lr", float(v)))
+    momentum = property(lambda self: self._hyper["momentum"], lambda self, v: self._set_hyper("momentum", float(v)))
+    weight_decay = property(lambda self: self._hyper["weight_decay"], lambda self, v: self._set_hyper("weight_decay", float(v)))
+    max_grad_norm = property(lambda self: self._hyper["max_grad_norm"], lambda self, v: self._set_hyper("max_grad_norm", float(v)))
+
+    def set_lr(self, lr: float) -> None:
+        """Learning rate for the following steps (a scheduler's hook)."""
+        self.lr = lr
 
     # ------------------------------------------------------------------ kernel sequences
     def _cls_params(self):
@@ -376,16 +401,20 @@ class NnueTrainer:
         main.wait_stream(s1)
         main.wait_stream(s2)
 
-    def _plans(self):
+    def _plans(self, slot: int = 0):
         """Records the three fixed call sequences once (this also executes them once; the update plans are
-        recorded on throw-away copies of the buffers' contents, which are restored afterwards)."""
+        recorded on throw-away copies of the buffers' contents, which are restored afterwards).  The local plan is
+        recorded on the input slot of the step that triggers it (no other slot is read or written)."""
         if self._plan_local is None:
             self._plan_seg = {}
+            self._plan_slot = slot
+            self.images, self.labels = self.inputs[slot]
             for name in self.SEGMENTS:
                 with lib.record_calls() as calls:
                     self._segment(name)
                 self._plan_seg[name] = list(calls)
             self._plan_local = [c for name in self.SEGMENTS for c in self._plan_seg[name]]
+        if self._plan_update is None:
             live = [self.flat_params, self.flat_grads, self.grad_norm] + self._optimizer_buffers()
             keep = [t.clone() for t in live]  # recording executes the updates: put everything back afterwards
             with lib.record_calls() as calls:
@@ -399,12 +428,13 @@ class NnueTrainer:
         return self._plan_local, self._plan_update_first, self._plan_update
 
     def _seg_plan(self, slot: int, name: str):
-        """The recorded calls of one segment with slot 0's input pointers swapped for `slot`'s."""
+        """The recorded calls of one segment with the recorded slot's input pointers swapped for `slot`'s."""
         plan = self._plan_seg[name]
-        if slot == 0:
+        src = self._plan_slot
+        if slot == src:
             return plan
-        swap = {self.inputs[0][0].data_ptr(): self.inputs[slot][0].data_ptr(),
-                self.inputs[0][1].data_ptr(): self.inputs[slot][1].data_ptr()}
+        swap = {self.inputs[src][0].data_ptr(): self.inputs[slot][0].data_ptr(),
+                self.inputs[src][1].data_ptr(): self.inputs[slot][1].data_ptr()}
         return [(nm, fn, tuple(swap.get(a, a) if isinstance(a, int) else a for a in args)) for nm, fn, args in plan]
 
     # ------------------------------------------------------------------ public
@@ -437,10 +467,7 @@ class NnueTrainer:
                 buf_images[:n].copy_(images, non_blocking=True)
                 buf_labels.fill_(-1)
                 buf_labels[:n].copy_(labels, non_blocking=True)
-        if self._plan_local is None and slot != 0:
-            self.inputs[0][0].copy_(buf_images)
-            self.inputs[0][1].copy_(buf_labels)
-        _, upd_first, upd = self._plans()
+        _, upd_first, upd = self._plans(slot)
         first = self.steps_done == 0
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         graphs = self.use_graph and timers is None
@@ -530,7 +557,7 @@ class NnueTrainer:
     @torch.no_grad()
     def evaluate(self, images: torch.Tensor) -> torch.Tensor:
         """Forward only on a full-size batch; returns logits (a view of the static buffer)."""
-        self.inputs[0][0].copy_(images, non_blocking=True)
+        self.images.copy_(images, non_blocking=True)  # the slot the eager segments read (slot 0 unless a plan was recorded elsewhere)
         self._forward()
         return self.logits
 

@@ -2,6 +2,7 @@
 implementation.  The metric arithmetic and the host bookkeeping run everywhere; the HIP confusion kernel and
 the whole evaluate_model loop need the GPU."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -70,6 +71,18 @@ def test_evaluate_model_matches_reference():
     check(metrics, z["metrics"], "evaluate_model")  # same predictions -> identical metrics
     with pytest.raises(ValueError):
         evaluate.evaluate_model(model, [], None)
+    # a label outside [0, C) is an error (F.cross_entropy would raise, sklearn would count it), not a silently skipped sample
+    bad = [(loader[0][0], loader[0][1].clone())]
+    bad[0][1][3] = cfg["classes"] + 2
+    for graph in ("1", "0"):
+        os.environ["NNUE_EVAL_GRAPH"] = graph
+        try:
+            with pytest.raises(ValueError, match="labels lie outside"):
+                evaluate.evaluate_model(model, bad, None, torch.device("cuda"))
+        finally:
+            os.environ.pop("NNUE_EVAL_GRAPH")
+    with pytest.raises(ValueError, match="labels lie outside"):
+        evaluate.compute_metrics(torch.randn(4, 3).cuda(), torch.tensor([0, 1, 7, 2]).cuda())
 
 
 @pytest.mark.gpu

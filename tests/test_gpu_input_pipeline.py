@@ -126,6 +126,11 @@ def test_trainer_consumes_pipeline_batches_in_place():
     assert all(np.isfinite(losses)) and len(losses) == 8
     with pytest.raises(ValueError):
         GpuImageDataset(np.zeros((4, 8, 8), dtype=np.uint8), np.zeros(4))
+    # labels are validated once at construction (inside the step only the -1 padding sentinel is ignored)
+    with pytest.raises(ValueError, match="labels must lie"):
+        GpuImageDataset(images, np.where(np.arange(256) == 7, -1, labels))
+    with pytest.raises(ValueError, match="labels must lie"):
+        GpuImageDataset(images, labels, num_classes=int(np.asarray(labels).max()))
     with pytest.raises(lib.NnueHipError):
         lib.load_batch(torch.zeros(4, 8, 8, 3, dtype=torch.uint8), torch.zeros(4, dtype=torch.int64), torch.zeros(2, dtype=torch.int64), False, 0, 0)
 

@@ -138,3 +138,32 @@ def test_density_sweep_step_against_oracle(monkeypatch, density, path):
     grads = tr.layout.views(tr.flat_grads)
     for k, ref in ref_grads.items():
         assert_close_grad(grads[k], ref, f"{k} density={density}")
+
+
+def test_first_step_on_another_slot_leaves_slot_zero_alone_and_lr_changes_take_effect():
+    """recording the plan on the slot of the first step (not on a copy into slot 0); a changed learning rate
+    re-records the update plan and the graphs built from it."""
+    torch.manual_seed(0)
+    model = nnue.NNUE(nnue.GridFeatureSet(10, 8), 256, 32, 16, num_classes=10).to(DEV)
+    twin = nnue.NNUE(nnue.GridFeatureSet(10, 8), 256, 32, 16, num_classes=10).to(DEV)
+    twin.load_state_dict(model.state_dict())
+    gen = torch.Generator().manual_seed(4)
+    data = [(torch.randn(32, 3, 32, 32, generator=gen).to(DEV), torch.randint(0, 10, (32,), generator=gen).to(DEV)) for _ in range(3)]
+    tr = NnueTrainer(model, 32, (32, 32), lr=0.05, momentum=0.9, input_slots=3, use_graph=True)
+    for (im, lb), (ti, tl) in zip(data, tr.inputs):
+        ti.copy_(im)
+        tl.copy_(lb)
+    tr.step(slot=2)  # first step ever, not on slot 0
+    assert torch.equal(tr.inputs[0][0], data[0][0]) and torch.equal(tr.inputs[0][1], data[0][1])
+    tr.step(slot=0)
+    tr.step(slot=1)
+    tr.lr = 0.5  # same as set_lr(0.5)
+    tr.step(slot=2)
+    tr.step(slot=0)
+    ref = NnueTrainer(twin, 32, (32, 32), lr=0.05, momentum=0.9, use_graph=False)
+    for i, slot in enumerate((2, 0, 1, 2, 0)):
+        if i == 3:
+            ref.set_lr(0.5)
+        ref.step(*data[slot])
+    assert_close_grad(tr.flat_params, ref.flat_params, "parameters after an lr change", rtol=1e-6)
+    assert_close_grad(tr.evaluate(data[1][0]), ref.evaluate(data[1][0]), "evaluate after a plan recorded on slot 2", rtol=1e-6)
