@@ -191,12 +191,16 @@ def main():
     if args.density is not None:
         if not 0.0 < args.density < 1.0:
             raise SystemExit("--density must be in (0, 1)")
-        with torch.no_grad():  # per-channel quantile of this rank's conv outputs on slot 0
-            conv = torch.nn.functional.conv2d(trainer.inputs[0][0][:min(B, 64)], model.conv.weight.detach(), stride=model.conv.stride, padding=1)
-            per_channel = conv.transpose(0, 1).flatten(1)
-            if per_channel.shape[1] > 1 << 20:
-                per_channel = per_channel[:, :: per_channel.shape[1] // (1 << 20) + 1]
-            model.visual_threshold.copy_(torch.quantile(per_channel, 1.0 - args.density, dim=1))
+        with torch.no_grad():  # per-channel quantile of this rank's conv outputs over every input slot
+            convs = [torch.nn.functional.conv2d(im, model.conv.weight.detach(), stride=model.conv.stride, padding=1).transpose(0, 1).flatten(1)
+                     for im, _ in trainer.inputs]
+            per_channel = torch.cat(convs, dim=1)
+            if per_channel.shape[1] > 1 << 22:
+                per_channel = per_channel[:, :: per_channel.shape[1] // (1 << 22) + 1]
+            model.visual_threshold.copy_(torch.stack([torch.quantile(c, 1.0 - args.density) for c in per_channel]))
+        # the sweep point must stay where it was put: training would move the thresholds (r1: 0.01 requested -> 0.07
+        # realised after 220 steps), so the sweep runs the identical kernels with a zero learning rate
+        trainer.lr = 0.0
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -325,6 +329,8 @@ def main():
                 with torch.no_grad():
                     model_g.visual_threshold.copy_(model.visual_threshold)
             tg = NnueTrainer(model_g, B, (cfg["image"], cfg["image"]), group=None, use_graph=not args.no_graph, input_slots=SLOTS, **OPT)
+            if args.density is not None:
+                tg.lr = 0.0
             if tg.ft_path == "bits":
                 for (gi, gl), (si, sl) in zip(tg.inputs, trainer.inputs):
                     gi.copy_(si)
@@ -391,7 +397,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: NNUE {cfg['image']}x{cfg['image']} grid {cfg['grid']}x{cfg['grid']}x{cfg['fps']} "
                                    f"F={cfg['grid'] ** 2 * cfg['fps']} -> {cfg['l1']}/{cfg['l2']}/{cfg['l3']} -> {cfg['classes']}, "
-                                   f"batch {B}/GPU, SGD m0.9 wd2e-4 clip1.0" + (f", thresholds set for density {args.density}" if args.density is not None else ""),
+                                   f"batch {B}/GPU, SGD m0.9 wd2e-4 clip1.0" + (f", thresholds set for density {args.density} and held (lr 0)" if args.density is not None else ""),
                        "global_batch": B * world, "parallelism": f"dp{world}", "launch": "eager" if args.no_graph else "hipGraph",
                        "mean_active_features": round(n_mean, 1), "max_active_features": n_max,
                        "active_density": round(n_mean / ((cfg["image"] - 1) // max(1, (cfg["image"] - 1) // (cfg["grid"] - 1)) + 1) ** 2 / cfg["fps"], 4),

@@ -1,0 +1,100 @@
+"""The step bench.py times -- NnueTrainer with its default flags under hipGraph replay (fused conv+map, FT forward with
+the layer-1 slabs in its epilogue, merged FT backward with the d_w1 rider and the norm partials, deferred STE stage 2,
+fused clip + SGD) -- at the BASELINE shapes themselves, three optimizer steps against the CPU oracle's explicit chain
+(oracle.loss_and_grads_explicit + oracle.sgd_step; train.py:359-366).  ``-m gpu``.
+
+The step has two kinds of discontinuity, and a float32 result on either side of one is equally "right":
+``conv_out > thr`` (bit-exact feature ids need identical decisions; the oracle's MKL-DNN conv sums in another order than
+ours, ~1e-7 relative) and the ReLU gates ``z > 0`` of the classifier's backward (found at the 224x224 shape: one
+pre-activation of 16 384 at -2e-5 against a scale of 400 and a float32 summation error of 4e-4 flipped its gate and
+moved d_w1 by 1.4 % of its maximum, with loss and logits unchanged).  Every batch is therefore drawn so that *for the
+parameters of the step it is used in* no conv output lies within 1e-5 of its threshold and no pre-activation within
+2e-5 x (largest pre-activation of its layer) of zero; samples that do are redrawn.  The margin check runs in float64 on
+the CPU.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import nnue
+import nnue_oracle as orc
+from conftest import assert_close_grad
+from nnue_hip.trainer import NnueTrainer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+OPT = dict(lr=0.01, momentum=0.9, weight_decay=2e-4, max_grad_norm=1.0)  # config/train_nnue.py:29-36
+
+SHAPES = {
+    # BASELINE configs[1], [2] (K = 1 form), [3]                                   
+    "c2": dict(grid=10, fps=8, image=32, l1=1024, l2=128, l3=32, classes=10, batch=512),
+    "c3": dict(grid=10, fps=8, image=32, l1=1024, l2=128, l3=32, classes=100, batch=1024),
+    "c4": dict(grid=32, fps=64, image=224, l1=1024, l2=128, l3=32, classes=1000, batch=128),
+}
+
+
+def clean_batch(cfg, params, stride, gen, margin=1e-5, gate_margin=2e-5):
+    """randn images / randint labels that keep the margins described above."""
+    b, hw = cfg["batch"], cfg["image"]
+    images = torch.randn(b, 3, hw, hw, generator=gen)
+    p64 = {k: v.double() for k, v in params.items()}
+    t64 = p64["visual_threshold"].view(1, -1, 1, 1)
+    for _ in range(64):
+        x = F.conv2d(images.double(), p64["conv.weight"], stride=stride, padding=1)
+        dirty = ((x - t64).abs() < margin).flatten(1).any(dim=1)
+        idx, _ = orc.active_lists(x, p64["visual_threshold"])
+        l0 = orc.pairwise(orc.ft_forward(p64["input.weight"], p64["input.bias"], idx, (idx >= 0).double()))
+        z1 = F.linear(l0, p64["classifier.classifier.0.weight"], p64["classifier.classifier.0.bias"])
+        z2 = F.linear(F.relu(z1), p64["classifier.classifier.2.weight"], p64["classifier.classifier.2.bias"])
+        for z in (z1, z2):
+            dirty |= (z.abs() < gate_margin * float(z.abs().max())).any(dim=1)
+        if not bool(dirty.any()):
+            break
+        images[dirty] = torch.randn(int(dirty.sum()), 3, hw, hw, generator=gen)
+    else:
+        raise AssertionError("could not draw a batch that keeps the margins")
+    return images, torch.randint(0, cfg["classes"], (b,), generator=gen)
+
+
+@pytest.mark.parametrize("name", ("c2", "c3", "c4"))
+def test_three_steps_at_the_baseline_shape_follow_the_oracle(name):
+    cfg = SHAPES[name]
+    torch.manual_seed(0)
+    model = nnue.NNUE(nnue.GridFeatureSet(cfg["grid"], cfg["fps"]), cfg["l1"], cfg["l2"], cfg["l3"],
+                      num_classes=cfg["classes"], input_size=cfg["image"])
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    stride = orc.conv_stride(cfg["image"], cfg["grid"])
+    model = model.to(DEV)
+    tr = NnueTrainer(model, cfg["batch"], (cfg["image"], cfg["image"]), use_graph=True, input_slots=2, **OPT)
+    # the path under test is the one the bench line reports
+    assert tr.ft_path == "mfma" and tr.use_graph
+    if name in ("c2", "c3"):
+        assert tr.fuse_l1 and tr.ride_dw1 and tr.defer_ste and tr.merge_backward
+    gen = torch.Generator().manual_seed(77)
+    bufs = {}
+    for s in range(3):
+        images, labels = clean_batch(cfg, params, stride, gen)
+        before = {k: v.clone() for k, v in params.items()}
+        _, ref_loss, ref_grads, keep = orc.loss_and_grads_explicit(params, images, labels, stride)
+        ref_norm = orc.sgd_step(params, ref_grads, bufs, OPT["lr"], OPT["momentum"], OPT["weight_decay"], OPT["max_grad_norm"])
+        slot = s % 2  # steps 1.. replay the captured full-step graph, on alternating input slots
+        was = {k: v.detach().clone() for k, v in tr.p.items()}
+        loss = tr.step(images.to(DEV), labels.to(DEV), slot=slot)
+        torch.cuda.synchronize()
+        n_mean, n_max = tr.active_stats()
+        assert n_max == int(keep["n"].max()) and abs(n_mean - float(keep["n"].float().mean())) < 1e-2, "feature counts differ"
+        assert abs(float(loss) - float(ref_loss)) <= 1e-4 * max(1.0, abs(float(ref_loss))), (s, float(loss), float(ref_loss))
+        assert abs(float(tr.grad_norm) - float(ref_norm)) <= 1e-4 * float(ref_norm), (s, float(tr.grad_norm), float(ref_norm))
+        if getattr(tr, "grads_materialised", True):
+            got = tr.layout.views(tr.flat_grads)
+            for k, ref in ref_grads.items():
+                assert_close_grad(got[k], ref, f"{name} step {s} grad {k}")
+        for k in orc.TRAINABLE_KEYS:
+            # the parameters themselves and, much sharper, what the step changed
+            assert_close_grad(tr.p[k], params[k], f"{name} step {s} {k}", rtol=1e-5)
+            got_d, ref_d = (tr.p[k] - was[k]).cpu().double(), (params[k] - before[k]).double()
+            # a float32 parameter cannot move by less than its own rounding: two ulps of the largest entry are the floor
+            floor = 2 * 2.0 ** -23 * float(params[k].abs().max())
+            err, scale = float((got_d - ref_d).abs().max()), float(ref_d.abs().max())
+            assert err <= 2e-4 * scale + floor, f"{name} step {s} update of {k}: err {err:.3e}, scale {scale:.3e}, floor {floor:.1e}"
+    assert float(model.nnue2score) == 600.0

@@ -112,11 +112,11 @@ def thresholds_for_density(model, images, density):
         return torch.quantile(per_channel, 1.0 - density, dim=1)
 
 
-@pytest.mark.parametrize("path", ("bits", "list"))
+@pytest.mark.parametrize("path", ("mfma", "bits", "list"))
 @pytest.mark.parametrize("density", (0.01, 0.05, 0.25, 0.9))
 def test_density_sweep_step_against_oracle(monkeypatch, density, path):
     """Whole-step gradients at about 1 %, 5 %, 25 % and 90 % active features (the sweep SURVEY 8d asks for, after the
-    reference's tests/test_model.py:570-576), both FeatureTransformer kernel families, against the CPU oracle."""
+    reference's tests/test_model.py:570-576), the shipped product form and both gather families, against the CPU oracle."""
     import nnue_oracle as orc
     monkeypatch.setenv("NNUE_FT_PATH", path)
     torch.manual_seed(2)
@@ -128,7 +128,7 @@ def test_density_sweep_step_against_oracle(monkeypatch, density, path):
     params = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model = model.to(DEV)
     tr = NnueTrainer(model, 48, (32, 32), lr=0.0, use_graph=False)
-    assert tr.use_bits == (path == "bits")
+    assert tr.ft_path == path
     loss = tr.step(images.to(DEV), labels.to(DEV))
     _, ref_loss, ref_grads, keep = orc.loss_and_grads_explicit(params, images, labels, 3)
     n_mean, n_max = tr.active_stats()
