@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 18
+#define NNUE_HIP_ABI_VERSION 19
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -313,6 +313,70 @@ int nnue_classifier_train_step(const float* x, int pairwise,
                                float* d_x, float* d_w1, float* d_b1, float* d_w2, float* d_b2,
                                float* d_w3, float* d_b3,
                                void* scratch, int64_t scratch_bytes, int phases, nnue_stream_t stream);
+
+/* ---- bucketed layer stacks (build extension; BASELINE configs[2]) -------------------------------------------------
+ *
+ * The reference trains ONE SimpleClassifier (nnue.py:713-738; serialize.py:57 writes num_ls_buckets = 1) while its
+ * engine still loads N LayerStacks (engine/src/nnue_engine.cpp:619-635).  K > 1 here = K independent weight sets
+ * w1 [K][L2][L1], b1 [K][L2], w2 [K][L3][L2], b2 [K][L3], w3 [K][C][L3], b3 [K][C], one selected per sample:
+ *     bucket[b] = min(K-1, n[b] * K / (P + 1)),  n[b] = active features of sample b, P = flat ids of the map
+ * -- a by-product of the binarise kernels.  There is no reference for K > 1 (parity unpinned; oracle/nnue_oracle.py
+ * holds the CPU restatement); with K == 1 every *_bucketed entry point is exactly its plain counterpart.
+ * nnue_bucket_group sorts the samples by bucket (stable) into bucket-homogeneous 16-row tiles so that each MFMA
+ * tile of the first layer multiplies by one bucket's weights:
+ *     rows[16 t + i]   sample in row i of tile t (-1 = padding)     tile_bucket[t]  its bucket (-1 = unused tile)
+ *     seg[k], seg[k+1] row range of bucket k (multiples of 16)      t < nnue_bucket_tile_count(B, K) = ceil(B/16) + K
+ * All arrays are int32 device memory; the struct itself is read on the host. */
+typedef struct nnue_buckets {
+  int32_t K;                  /* layer stacks; <= 1: single stack, pointers ignored */
+  const int32_t* bucket;      /* [B] */
+  const int32_t* rows;        /* [tiles * 16] */
+  const int32_t* tile_bucket; /* [tiles] */
+  const int32_t* seg;         /* [K + 1] */
+  int32_t tiles;              /* nnue_bucket_tile_count(B, K) */
+} nnue_buckets;
+
+int nnue_bucket_tile_count(int B, int K);
+/* Selector + grouping in one single-workgroup launch (the K = 1 case of the structure is nnue.py:713-738; header field
+ * serialize.py:57).  P == 0: n[b] is taken as the bucket itself (clamped to [0, K-1]) -- the stand-alone classifier
+ * call.  K <= 64. */
+int nnue_bucket_group(const int32_t* n, int B, int P, int K, int32_t* bucket, int32_t* rows,
+                      int32_t* tile_bucket, int32_t* seg, nnue_stream_t stream);
+
+/* nnue_classifier_forward / _backward / _train_step (nnue.py:660-666, :728-734 and their autograd) with stacked
+ * weights and gradients [K][...] and the grouping above.  train_step: phases bits 8 and 16 are refused for K > 1
+ * (those products live in the FeatureTransformer launches, which know one stack).  d_w1 of a bucket is summed over
+ * slices of that bucket's own rows; scratch sizes from the *_scratch_bucketed functions. */
+int64_t nnue_classifier_scratch_bucketed(int B, int L1, int L2, int L3, int K);
+int64_t nnue_classifier_train_scratch_bucketed(int B, int L1, int L2, int L3, int C, int K);
+int nnue_classifier_forward_bucketed(const float* x, int pairwise,
+                                     const float* w1, const float* b1, const float* w2, const float* b2,
+                                     const float* w3, const float* b3, float clip,
+                                     int B, int L1, int L2, int L3, int C,
+                                     float* h1, float* h2, float* logits,
+                                     void* scratch, int64_t scratch_bytes, const nnue_buckets* buckets,
+                                     nnue_stream_t stream);
+/* autograd of the bucketed forward (nnue.py:728-734 per stack): gradients [K][...], d_x [B][L1]. */
+int nnue_classifier_backward_bucketed(const float* x, int pairwise,
+                                      const float* w1, const float* w2, const float* w3, float clip,
+                                      const float* h1, const float* h2, const float* d_logits,
+                                      int B, int L1, int L2, int L3, int C,
+                                      float* d_x, float* d_w1, float* d_b1, float* d_w2, float* d_b2,
+                                      float* d_w3, float* d_b3,
+                                      void* scratch, int64_t scratch_bytes, const nnue_buckets* buckets,
+                                      nnue_stream_t stream);
+/* forward + mean cross-entropy + backward of the bucketed block in one call (train.py:250-254, :360-361 on top of
+ * nnue.py:728-734 per stack). */
+int nnue_classifier_train_step_bucketed(const float* x, int pairwise,
+                                        const float* w1, const float* b1, const float* w2, const float* b2,
+                                        const float* w3, const float* b3, float clip,
+                                        const int64_t* labels, float grad_scale,
+                                        int B, int L1, int L2, int L3, int C,
+                                        float* h1, float* h2, float* logits, float* sample_loss, float* loss,
+                                        float* d_x, float* d_w1, float* d_b1, float* d_w2, float* d_b2,
+                                        float* d_w3, float* d_b3,
+                                        void* scratch, int64_t scratch_bytes, int phases,
+                                        const nnue_buckets* buckets, nnue_stream_t stream);
 
 /* ---- loss + step tail ---------------------------------------------------------- */
 

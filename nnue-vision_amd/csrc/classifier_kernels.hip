@@ -14,6 +14,24 @@ namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+// Bucketed layer stacks (build extension, SURVEY section 7 / BASELINE configs[2]: K independent SimpleClassifier weight
+// sets [K][out][in], one selected per sample by its active-feature count -- the vision analogue of the piece-count
+// buckets the engine's LayerStack vector descends from, engine/src/nnue_engine.cpp:619-635).  K == 1 with null pointers
+// is the reference's single stack and takes exactly the code it always took.  nnue_bucket_group sorts the samples by
+// bucket into 16-row tiles, so that every MFMA tile multiplies by ONE bucket's weights ("batched per-bucket MFMA"):
+//   bucket[b]         bucket of sample b
+//   rows[16 t + i]    sample in row i of tile t, ascending inside a bucket; -1 = padding
+//   tile_bucket[t]    bucket of tile t; -1 = unused tile
+//   seg[k], seg[k+1]  row range (multiples of 16) of bucket k
+struct Buckets {
+  int K;
+  const int* bucket;
+  const int* rows;
+  const int* tile_bucket;
+  const int* seg;
+  int tiles;
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
@@ -38,13 +56,13 @@ __device__ __forceinline__ float l0_at(const float* __restrict__ xr, int k, int 
 // wave per output (b, j): lanes stride over K; pre-activation, bias not yet added.
 __global__ __launch_bounds__(256) void l1_forward_simple(const float* __restrict__ x, int pairwise,
                                                          const float* __restrict__ w1, int B, int L1, int L2,
-                                                         float* __restrict__ part) {
+                                                         float* __restrict__ part, Buckets bk) {
   const long long o = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (o >= (long long)B * L2) return;
   const int b = (int)(o / L2), j = (int)(o - (long long)b * L2);
   const int lane = threadIdx.x & 63, half = L1 / 2;
   const float* __restrict__ xr = x + (size_t)b * L1;
-  const float* __restrict__ wr = w1 + (size_t)j * L1;
+  const float* __restrict__ wr = w1 + ((size_t)(bk.bucket ? bk.bucket[b] : 0) * L2 + j) * L1;
   float acc = 0.f;
   for (int k = lane; k < L1; k += 64) acc = fmaf(l0_at(xr, k, half, pairwise), wr[k], acc);
   acc = wave_sum(acc);
@@ -54,25 +72,33 @@ __global__ __launch_bounds__(256) void l1_forward_simple(const float* __restrict
 // d_w1[i, j] = sum_b d_z1[b, i] * l0[b, j]; thread per (i, j)
 __global__ __launch_bounds__(256) void l1_backward_w_simple(const float* __restrict__ x, int pairwise,
                                                             const float* __restrict__ d_z1, int B, int L1, int L2,
-                                                            float* __restrict__ d_w1) {
-  const int i = blockIdx.x;
+                                                            float* __restrict__ d_w1, Buckets bk) {
+  const int i = blockIdx.x % L2, kb = blockIdx.x / L2;  // grid.x = K * L2
   const int j = blockIdx.y * 256 + threadIdx.x;
   if (j >= L1) return;
   const int half = L1 / 2;
   float acc = 0.f;
-  for (int b = 0; b < B; ++b) acc = fmaf(d_z1[(size_t)b * L2 + i], l0_at(x + (size_t)b * L1, j, half, pairwise), acc);
-  d_w1[(size_t)i * L1 + j] = acc;
+  if (bk.rows) {  // the samples of bucket kb, ascending
+    for (int g = bk.seg[kb]; g < bk.seg[kb + 1]; ++g) {
+      const int b = bk.rows[g];
+      if (b >= 0) acc = fmaf(d_z1[(size_t)b * L2 + i], l0_at(x + (size_t)b * L1, j, half, pairwise), acc);
+    }
+  } else {
+    for (int b = 0; b < B; ++b) acc = fmaf(d_z1[(size_t)b * L2 + i], l0_at(x + (size_t)b * L1, j, half, pairwise), acc);
+  }
+  d_w1[((size_t)kb * L2 + i) * L1 + j] = acc;
 }
 
 // d_l0 = d_z1 W1, then the pairwise block's own backward; thread per (b, j)
 __global__ __launch_bounds__(256) void l1_backward_x_simple(const float* __restrict__ x, int pairwise,
                                                             const float* __restrict__ w1,
                                                             const float* __restrict__ d_z1, int B, int L1, int L2,
-                                                            float* __restrict__ d_x) {
+                                                            float* __restrict__ d_x, Buckets bk) {
   const int b = blockIdx.x;
   const int j = blockIdx.y * 256 + threadIdx.x;
   const int half = L1 / 2;
   const float* __restrict__ dz = d_z1 + (size_t)b * L2;
+  if (bk.bucket) w1 += (size_t)bk.bucket[b] * L2 * L1;
   if (pairwise) {
     if (j >= half) return;
     float lo = 0.f, hi = 0.f;
@@ -102,12 +128,12 @@ constexpr int kFwdTileN = 4;  // 16x16 tiles along L2 per wave
 
 __global__ __launch_bounds__(256) void l1_forward_mfma(const float* __restrict__ x, int pairwise,
                                                        const float* __restrict__ w1, int B, int L1, int L2,
-                                                       int ksplit, float* __restrict__ part) {
+                                                       int ksplit, float* __restrict__ part, Buckets bk) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, q = lane >> 4;
   const int n_groups = (L2 + 16 * kFwdTileN - 1) / (16 * kFwdTileN);
-  const int m_tiles = (B + 15) / 16;
+  const int m_tiles = bk.rows ? bk.tiles : (B + 15) / 16;
   long long wid = (long long)blockIdx.x * 4 + wave;
   if (wid >= (long long)m_tiles * n_groups * ksplit) return;
   const int ks = (int)(wid % ksplit);
@@ -117,8 +143,19 @@ __global__ __launch_bounds__(256) void l1_forward_mfma(const float* __restrict__
   const int klen = L1 / ksplit;  // multiple of 16, inside one half when pairwise (ksplit even)
   const int k_lo = ks * klen;
   const int half = L1 / 2;
-  const int row = mt * 16 + r;
-  const bool row_ok = row < B;
+  int row = mt * 16 + r;
+  int orow[4];  // sample behind accumulator register e (row 4 q + e of the tile)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) orow[e] = mt * 16 + 4 * q + e;
+  if (bk.rows) {  // a tile of one bucket: its rows are samples gathered by the grouping, its weights that bucket's
+    const int kb = bk.tile_bucket[mt];  // wave-uniform
+    if (kb < 0) return;
+    w1 += (size_t)kb * L2 * L1;
+    row = bk.rows[row];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) orow[e] = bk.rows[orow[e]];
+  }
+  const bool row_ok = row >= 0 && row < B;
   const float* __restrict__ xr = x + (size_t)(row_ok ? row : 0) * L1;
   // pairwise: first half of l0 = x[k] * x[k + half]; second half = x[k - half]
   const bool prod = pairwise && k_lo < half;
@@ -178,10 +215,8 @@ __global__ __launch_bounds__(256) void l1_forward_mfma(const float* __restrict__
     const int col = (ng * kFwdTileN + t) * 16 + r;
     if (col >= L2) continue;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int orow = mt * 16 + 4 * q + e;
-      if (orow < B) out[(size_t)orow * L2 + col] = acc[t][e];
-    }
+    for (int e = 0; e < 4; ++e)
+      if (orow[e] >= 0 && orow[e] < B) out[(size_t)orow[e] * L2 + col] = acc[t][e];
   }
 }
 
@@ -190,23 +225,33 @@ __global__ __launch_bounds__(256) void l1_forward_mfma(const float* __restrict__
 // lane loads one dword per tile row/column block.
 constexpr int kBwTileM = 2, kBwTileN = 4;
 
+// Bucketed (bk.rows): a wave owns the same tile of ONE bucket's d_w1 and slice ks of that bucket's row range
+// [seg[kb] + ks*klen, .. + klen); a slice that starts past the bucket's end writes nothing (the slab sum knows, see
+// bucket_slabs).  Slab layout [ksplit][K * L2 * L1].
 __device__ __forceinline__ void l1_backward_w_body(const float* __restrict__ x, int pairwise, const float* __restrict__ d_z1,
                                                    int B, int L1, int L2, int ksplit, int klen, float* __restrict__ part,
-                                                   long long block) {
+                                                   long long block, const Buckets& bk) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, q = lane >> 4;
   const int m_groups = L2 / (16 * kBwTileM);  // L2 % 32 == 0
   const int n_groups = L1 / (16 * kBwTileN);  // L1 % 64 == 0
   long long wid = block * 4 + wave;
-  if (wid >= (long long)m_groups * n_groups * ksplit) return;
+  if (wid >= (long long)m_groups * n_groups * ksplit * bk.K) return;
   const int ks = (int)(wid % ksplit);
   wid /= ksplit;
   const int ng = (int)(wid % n_groups);
-  const int mg = (int)(wid / n_groups);
+  wid /= n_groups;
+  const int mg = (int)(wid % m_groups);
+  const int kb = (int)(wid / m_groups);
   const int half = L1 / 2;
-  const int b_lo = ks * klen;
-  const int b_hi = min(B, b_lo + klen);
+  int b_lo = ks * klen, b_hi = min(B, b_lo + klen);
+  if (bk.rows) {
+    const int s_lo = bk.seg[kb], s_hi = bk.seg[kb + 1];
+    b_lo = s_lo + ks * klen;
+    b_hi = min(s_hi, b_lo + klen);
+    if (b_lo >= s_hi && !(ks == 0 && ksplit == 1)) return;  // empty slice; an unsplit product still writes its zeros
+  }
   f32x4 acc[kBwTileM][kBwTileN];
 #pragma unroll
   for (int i = 0; i < kBwTileM; ++i)
@@ -222,8 +267,12 @@ __device__ __forceinline__ void l1_backward_w_body(const float* __restrict__ x, 
     else { cj[t] = j - half; cj2[t] = -1; }
   }
   auto load_step = [&](int b0, float (&a)[kBwTileM], float (&bv)[kBwTileN]) {
-    const int b = b0 + q;
-    const bool ok = b < b_hi;
+    int b = b0 + q;
+    bool ok = b < b_hi;
+    if (bk.rows) {
+      b = ok ? bk.rows[b] : -1;
+      ok = b >= 0;
+    }
     const float* __restrict__ dz = d_z1 + (size_t)(ok ? b : 0) * L2 + mg * 16 * kBwTileM + r;
     const float* __restrict__ xr = x + (size_t)(ok ? b : 0) * L1;
 #pragma unroll
@@ -248,7 +297,7 @@ __device__ __forceinline__ void l1_backward_w_body(const float* __restrict__ x, 
         for (int t = 0; t < kBwTileN; ++t)
           acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], bv[u][t], acc[i][t], 0, 0, 0);
   }
-  float* __restrict__ out = part + (size_t)ks * L2 * L1;
+  float* __restrict__ out = part + ((size_t)ks * bk.K + kb) * L2 * L1;
 #pragma unroll
   for (int i = 0; i < kBwTileM; ++i)
 #pragma unroll
@@ -263,9 +312,18 @@ __device__ __forceinline__ void l1_backward_w_body(const float* __restrict__ x, 
 
 // fixed-order sum of split-K slabs: out[i] = sum_s part[s][i]
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ part, int slabs, long long count,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, Buckets bk, int klen) {
   const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= count) return;  // count % 4 == 0
+  if (bk.rows) {  // only the slices of this element's bucket that hold rows were written (l1_backward_w_body)
+    const int kb = (int)(i / (count / bk.K));
+    const int nz = (bk.seg[kb + 1] - bk.seg[kb] + klen - 1) / klen;
+    slabs = nz < slabs ? nz : slabs;
+    if (slabs == 0) {
+      *reinterpret_cast<float4*>(out + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+      return;
+    }
+  }
   float4 acc = *reinterpret_cast<const float4*>(part + i);
   for (int s = 1; s < slabs; ++s) {
     const float4 v = *reinterpret_cast<const float4*>(part + (size_t)s * count + i);
@@ -279,21 +337,32 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
 // needs both), adjacent tiles otherwise.
 __device__ __forceinline__ void l1_backward_x_body(const float* __restrict__ x, int pairwise, const float* __restrict__ w1,
                                                    const float* __restrict__ d_z1, int B, int L1, int L2,
-                                                   float* __restrict__ d_x, long long block) {
+                                                   float* __restrict__ d_x, long long block, const Buckets& bk) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, q = lane >> 4;
   const int half = L1 / 2;
   const int n_pairs = L1 / 32;
-  const int m_tiles = (B + 15) / 16;
+  const int m_tiles = bk.rows ? bk.tiles : (B + 15) / 16;
   const long long wid = block * 4 + wave;
   if (wid >= (long long)m_tiles * n_pairs) return;
   const int np = (int)(wid % n_pairs);
   const int mt = (int)(wid / n_pairs);
   const int c0 = pairwise ? np * 16 : np * 32;
   const int c1 = pairwise ? c0 + half : c0 + 16;
-  const int row = mt * 16 + r;
-  const bool row_ok = row < B;
+  int row = mt * 16 + r;
+  int orows[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) orows[e] = mt * 16 + 4 * q + e;
+  if (bk.rows) {  // tile of one bucket (see l1_forward_mfma)
+    const int kb = bk.tile_bucket[mt];
+    if (kb < 0) return;
+    w1 += (size_t)kb * L2 * L1;
+    row = bk.rows[row];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) orows[e] = bk.rows[orows[e]];
+  }
+  const bool row_ok = row >= 0 && row < B;
   const float* __restrict__ dz = d_z1 + (size_t)(row_ok ? row : 0) * L2;
   f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
   // K is walked in chunks of up to 4 blocks of 16; every load of a chunk is issued before its MFMAs, so a
@@ -329,8 +398,8 @@ __device__ __forceinline__ void l1_backward_x_body(const float* __restrict__ x, 
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const int orow = mt * 16 + 4 * q + e;
-    if (orow >= B) continue;
+    const int orow = orows[e];
+    if (orow < 0 || orow >= B) continue;
     float* __restrict__ o = d_x + (size_t)orow * L1;
     if (pairwise) {
       const float* __restrict__ xr = x + (size_t)orow * L1;
@@ -345,15 +414,15 @@ __device__ __forceinline__ void l1_backward_x_body(const float* __restrict__ x, 
 
 __global__ __launch_bounds__(256) void l1_backward_w_mfma(const float* __restrict__ x, int pairwise,
                                                           const float* __restrict__ d_z1, int B, int L1, int L2,
-                                                          int ksplit, int klen, float* __restrict__ part) {
-  l1_backward_w_body(x, pairwise, d_z1, B, L1, L2, ksplit, klen, part, blockIdx.x);
+                                                          int ksplit, int klen, float* __restrict__ part, Buckets bk) {
+  l1_backward_w_body(x, pairwise, d_z1, B, L1, L2, ksplit, klen, part, blockIdx.x, bk);
 }
 
 __global__ __launch_bounds__(256) void l1_backward_x_mfma(const float* __restrict__ x, int pairwise,
                                                           const float* __restrict__ w1,
                                                           const float* __restrict__ d_z1, int B, int L1, int L2,
-                                                          float* __restrict__ d_x) {
-  l1_backward_x_body(x, pairwise, w1, d_z1, B, L1, L2, d_x, blockIdx.x);
+                                                          float* __restrict__ d_x, Buckets bk) {
+  l1_backward_x_body(x, pairwise, w1, d_z1, B, L1, L2, d_x, blockIdx.x, bk);
 }
 
 // d_x and the d_w1 slabs in one launch: both only need d_z1, so the two small products share the chip instead of
@@ -362,9 +431,9 @@ __global__ __launch_bounds__(256) void l1_backward_x_mfma(const float* __restric
 __global__ __launch_bounds__(256) void l1_backward_xw_mfma(const float* __restrict__ x, int pairwise,
                                                            const float* __restrict__ w1, const float* __restrict__ d_z1,
                                                            int B, int L1, int L2, float* __restrict__ d_x, int w_blocks,
-                                                           int ksplit, int klen, float* __restrict__ part) {
-  if ((int)blockIdx.x < w_blocks) l1_backward_w_body(x, pairwise, d_z1, B, L1, L2, ksplit, klen, part, blockIdx.x);
-  else l1_backward_x_body(x, pairwise, w1, d_z1, B, L1, L2, d_x, (long long)blockIdx.x - w_blocks);
+                                                           int ksplit, int klen, float* __restrict__ part, Buckets bk) {
+  if ((int)blockIdx.x < w_blocks) l1_backward_w_body(x, pairwise, d_z1, B, L1, L2, ksplit, klen, part, blockIdx.x, bk);
+  else l1_backward_x_body(x, pairwise, w1, d_z1, B, L1, L2, d_x, (long long)blockIdx.x - w_blocks, bk);
 }
 
 // ------------------------------------------------------------------ narrow layers (per sample, LDS)
@@ -373,11 +442,15 @@ __global__ __launch_bounds__(128) void tail_forward_kernel(const float* __restri
                                                            const float* __restrict__ b2, const float* __restrict__ w3,
                                                            const float* __restrict__ b3, float clip, int B, int L2,
                                                            int L3, int C, float* __restrict__ h1,
-                                                           float* __restrict__ h2, float* __restrict__ logits) {
+                                                           float* __restrict__ h2, float* __restrict__ logits, Buckets bk) {
   extern __shared__ float lds[];  // h1 [L2], h2 [L3]
   float* h1s = lds;
   float* h2s = lds + L2;
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (bk.bucket) {  // this sample's layer stack
+    const int kb = bk.bucket[b];
+    b1 += (size_t)kb * L2; w2 += (size_t)kb * L3 * L2; b2 += (size_t)kb * L3; w3 += (size_t)kb * C * L3; b3 += (size_t)kb * C;
+  }
   for (int j = tid; j < L2; j += 128) {
     float z = b1[j];
     for (int s = 0; s < ksplit; ++s) z += part[((size_t)s * B + b) * L2 + j];
@@ -407,11 +480,15 @@ __global__ __launch_bounds__(128) void tail_backward_kernel(const float* __restr
                                                             const float* __restrict__ h1, const float* __restrict__ h2,
                                                             const float* __restrict__ w2, const float* __restrict__ w3,
                                                             float clip, int L2, int L3, int C,
-                                                            float* __restrict__ d_z1, float* __restrict__ d_z2) {
+                                                            float* __restrict__ d_z1, float* __restrict__ d_z2, Buckets bk) {
   extern __shared__ float lds[];  // d_logits [C], d_z2 [L3]
   float* dls = lds;
   float* dz2s = lds + C;
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (bk.bucket) {
+    const int kb = bk.bucket[b];
+    w2 += (size_t)kb * L3 * L2; w3 += (size_t)kb * C * L3;
+  }
   for (int c = tid; c < C; c += 128) dls[c] = d_logits[(size_t)b * C + c];
   __syncthreads();
   for (int j = tid; j < L3; j += 128) {
@@ -444,6 +521,8 @@ struct SmallWgrad {
   int n_slabs;
   long long slab_count;
   float* d_w1;
+  Buckets bk;    // bk.rows != NULL: every output exists once per bucket and sums over that bucket's samples
+  int bww_klen;  // rows per d_w1 slab slice (bucketed slab sum: slice s of bucket k is empty from s*klen >= its rows)
 };
 
 __device__ __forceinline__ void small_wgrad_body(const SmallWgrad& a, int blk) {
@@ -459,11 +538,20 @@ __device__ __forceinline__ void small_wgrad_body(const SmallWgrad& a, int blk) {
   float* __restrict__ d_w1 = a.d_w1;
   const int B = a.B, L2 = a.L2, L3 = a.L3, C = a.C, wgrad_blocks = a.wgrad_blocks, n_slabs = a.n_slabs;
   const long long slab_count = a.slab_count;
+  const Buckets& bk = a.bk;
   if (blk >= wgrad_blocks) {  // piggy-backed pass: fixed-order sum of the d_w1 split-K slabs
     const long long i = ((long long)(blk - wgrad_blocks) * 256 + threadIdx.x) * 4;
     if (i >= slab_count) return;
-    float4 acc = *reinterpret_cast<const float4*>(slabs + i);
-    for (int s2 = 1; s2 < n_slabs; ++s2) {
+    int nz = n_slabs;
+    if (bk.rows) {  // slices of this element's bucket that hold rows (the others were never written)
+      const int kb = (int)(i / (slab_count / bk.K));
+      const int len = bk.seg[kb + 1] - bk.seg[kb];
+      nz = (len + a.bww_klen - 1) / a.bww_klen;
+      nz = nz < n_slabs ? nz : n_slabs;
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nz > 0) acc = *reinterpret_cast<const float4*>(slabs + i);
+    for (int s2 = 1; s2 < nz; ++s2) {
       const float4 v = *reinterpret_cast<const float4*>(slabs + (size_t)s2 * slab_count + i);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
@@ -474,6 +562,19 @@ __device__ __forceinline__ void small_wgrad_body(const SmallWgrad& a, int blk) {
   const int lane = threadIdx.x & 63;
   const int v3 = (L3 % 4 == 0) ? 4 : 1, v2 = (L2 % 4 == 0) ? 4 : 1;
   const long long n_w3 = (long long)C * (L3 / v3), n_w2 = (long long)L3 * (L2 / v2);
+  const long long per = n_w3 + n_w2 + C + L3 + L2;  // outputs of one layer stack
+  int kb = 0, g_lo = 0, g_hi = B;
+  if (bk.rows) {
+    if (o < per * bk.K) {
+      kb = (int)(o / per);
+      o -= (long long)kb * per;
+      g_lo = bk.seg[kb];
+      g_hi = bk.seg[kb + 1];
+      d_w3 += (size_t)kb * C * L3; d_b3 += (size_t)kb * C; d_w2 += (size_t)kb * L3 * L2; d_b2 += (size_t)kb * L3; d_b1 += (size_t)kb * L2;
+    } else {
+      o = o - per * bk.K + per;  // the mean-loss wave behind the last stack
+    }
+  }
   const float* pa;
   const float* pb = nullptr;
   int sa, sb = 0, vec = 1;
@@ -502,7 +603,9 @@ __device__ __forceinline__ void small_wgrad_body(const SmallWgrad& a, int blk) {
   if (vec == 4) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
-    for (int b = lane; b < B; b += 64) {
+    for (int g = g_lo + lane; g < g_hi; g += 64) {
+      const int b = bk.rows ? bk.rows[g] : g;
+      if (b < 0) continue;
       const float a = pa[(size_t)b * sa];
       const float4 v = *reinterpret_cast<const float4*>(pb + (size_t)b * sb);
       acc.x = fmaf(a, v.x, acc.x); acc.y = fmaf(a, v.y, acc.y); acc.z = fmaf(a, v.z, acc.z); acc.w = fmaf(a, v.w, acc.w);
@@ -514,10 +617,16 @@ __device__ __forceinline__ void small_wgrad_body(const SmallWgrad& a, int blk) {
   float acc = 0.f;
   if (pb) {
 #pragma unroll 8
-    for (int b = lane; b < B; b += 64) acc = fmaf(pa[(size_t)b * sa], pb[(size_t)b * sb], acc);
+    for (int g = g_lo + lane; g < g_hi; g += 64) {
+      const int b = bk.rows ? bk.rows[g] : g;
+      if (b >= 0) acc = fmaf(pa[(size_t)b * sa], pb[(size_t)b * sb], acc);
+    }
   } else {
 #pragma unroll 8
-    for (int b = lane; b < B; b += 64) acc += pa[(size_t)b * sa];
+    for (int g = g_lo + lane; g < g_hi; g += 64) {
+      const int b = bk.rows ? bk.rows[g] : g;
+      if (b >= 0) acc += pa[(size_t)b * sa];
+    }
   }
   acc = wave_sum(acc);
   if (lane == 0) *dst = acc;
@@ -557,7 +666,7 @@ __global__ __launch_bounds__(NT) void tail_train_kernel(const float* __restrict_
                                                         int L2, int L3, int C, float* __restrict__ h1,
                                                         float* __restrict__ h2, float* __restrict__ logits,
                                                         float* __restrict__ sample_loss, float* __restrict__ d_logits,
-                                                        float* __restrict__ d_z1, float* __restrict__ d_z2) {
+                                                        float* __restrict__ d_z1, float* __restrict__ d_z2, Buckets bk) {
   extern __shared__ float lds[];  // h1 [L2] | h2 [L3] | logits / d_logits [C] | d_z2 [L3] | red [8]
   constexpr int S = NT / 32;      // class slices of the d_z2 sum
   __shared__ float part_s[S][32];
@@ -567,6 +676,10 @@ __global__ __launch_bounds__(NT) void tail_train_kernel(const float* __restrict_
   float* dz2s = lgs + C;
   float* red = dz2s + L3;
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (bk.bucket) {  // this sample's layer stack
+    const int kb = bk.bucket[b];
+    b1 += (size_t)kb * L2; w2 += (size_t)kb * L3 * L2; b2 += (size_t)kb * L3; w3 += (size_t)kb * C * L3; b3 += (size_t)kb * C;
+  }
   const int og = tid >> 2, part4 = tid & 3;
   // VEC (L2 % 4 == 0, L3 % 4 == 0, 16-byte aligned w2 / w3): a thread's share of a weight row is float4 runs, and the
   // first pass's runs are requested before the slab sum so that their latency hides behind it
@@ -743,13 +856,16 @@ struct ClsPlan {
   int bww_ksplit, bww_klen;  // batch slabs of d_w1
 };
 
-ClsPlan make_plan(int B, int L1, int L2, int pairwise) {
+constexpr int kMaxBuckets = 64;
+int bucket_tiles(int B, int K) { return (B + 15) / 16 + K; }  // sum_k ceil(c_k / 16) <= B / 16 + K
+
+ClsPlan make_plan(int B, int L1, int L2, int pairwise, int K = 1) {
   ClsPlan p{};
   p.fwd_mfma = (L1 % 32 == 0) && (L2 % 16 == 0);
   p.fwd_ksplit = 1;
   if (p.fwd_mfma) {
     // enough K slabs for >= ~1024 waves, each slab a multiple of 16 and (pairwise) inside one half
-    const int tiles = ((B + 15) / 16) * ((L2 + 63) / 64);
+    const int tiles = (K > 1 ? bucket_tiles(B, K) : (B + 15) / 16) * ((L2 + 63) / 64);
     int ks = 1;
     while (tiles * ks < 1024 && L1 % (ks * 2 * 16) == 0 && L1 / (ks * 2) >= 64) ks *= 2;
     if (pairwise && ks == 1) ks = 2;
@@ -758,7 +874,15 @@ ClsPlan make_plan(int B, int L1, int L2, int pairwise) {
   p.bww_mfma = (L1 % 64 == 0) && (L2 % 32 == 0);
   p.bww_ksplit = 1;
   p.bww_klen = B;
-  if (p.bww_mfma) {
+  if (p.bww_mfma && K > 1) {
+    // per bucket: slices of klen rows of its own segment; a bucket that holds every sample gets ks slices, one that
+    // holds B / K of them one -- the number of non-empty slices (= slabs written and summed) is <= ks + K
+    const int tiles = (L2 / 32) * (L1 / 64);
+    int ks = 1;
+    while (tiles * ks < 512 && B / (ks * 2) >= 64) ks *= 2;
+    p.bww_ksplit = ks;
+    p.bww_klen = (((B + ks - 1) / ks) + 15) / 16 * 16;
+  } else if (p.bww_mfma) {
     const int tiles = (L2 / 32) * (L1 / 64);
     int ks = 1;
     while (tiles * ks < 1024 && B / (ks * 2) >= 32) ks *= 2;
@@ -769,50 +893,211 @@ ClsPlan make_plan(int B, int L1, int L2, int pairwise) {
   return p;
 }
 
-int64_t plan_scratch_floats(const ClsPlan& p, int B, int L1, int L2, int L3) {
+int64_t plan_scratch_floats(const ClsPlan& p, int B, int L1, int L2, int L3, int K = 1) {
   const int64_t fwd = (int64_t)p.fwd_ksplit * B * L2;
-  const int64_t bwd = (int64_t)B * L2 + (int64_t)B * L3 + (p.bww_ksplit > 1 ? (int64_t)p.bww_ksplit * L2 * L1 : 0);
+  const int64_t bwd = (int64_t)B * L2 + (int64_t)B * L3 + (p.bww_ksplit > 1 ? (int64_t)p.bww_ksplit * K * L2 * L1 : 0);
   return (fwd > bwd ? fwd : bwd) + 64;
+}
+
+// ---- bucket selector + grouping (one workgroup; B a few thousand at most matters for speed, any B is correct) -----
+// bucket[b] = min(K-1, n[b] * K / (P + 1))  (P = flat ids of the map; P == 0: n[b] already IS the bucket, clamped)
+// then a stable counting sort of the samples into bucket-homogeneous 16-row tiles.
+__global__ __launch_bounds__(256) void bucket_group_kernel(const int* __restrict__ n, int B, int P, int K, int* __restrict__ bucket,
+                                                           int* __restrict__ rows, int* __restrict__ tile_bucket,
+                                                           int* __restrict__ seg, int tiles) {
+  __shared__ int cnt[kMaxBuckets], start[kMaxBuckets + 1], run[kMaxBuckets], wtot[4][kMaxBuckets];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto select = [&](int nb) {
+    int k = P > 0 ? (int)(((long long)nb * K) / ((long long)P + 1)) : nb;
+    k = k < 0 ? 0 : k;
+    return k < K - 1 ? k : K - 1;
+  };
+  if (tid < K) { cnt[tid] = 0; run[tid] = 0; }
+  __syncthreads();
+  for (int b = tid; b < B; b += 256) {
+    const int k = select(n[b]);
+    bucket[b] = k;
+    atomicAdd(&cnt[k], 1);  // integer: exact in any order
+  }
+  for (int i = tid; i < tiles * 16; i += 256) rows[i] = -1;
+  __syncthreads();
+  if (tid == 0) {
+    start[0] = 0;
+    for (int k = 0; k < K; ++k) start[k + 1] = start[k] + (cnt[k] + 15) / 16 * 16;
+  }
+  __syncthreads();
+  if (tid <= K) seg[tid] = start[tid];
+  for (int t = tid; t < tiles; t += 256) {
+    int kb = -1;
+    for (int k = 0; k < K; ++k)
+      if (16 * t >= start[k] && 16 * t < start[k] + cnt[k]) kb = k;
+    tile_bucket[t] = kb;
+  }
+  for (int chunk = 0; chunk < B; chunk += 256) {  // stable: ascending sample index inside a bucket
+    const int b = chunk + tid;
+    const int k = b < B ? select(n[b]) : -1;
+    int rank = 0;
+    for (int kk = 0; kk < K; ++kk) {
+      const unsigned long long m = __ballot(k == kk);
+      if (lane == 0) wtot[wave][kk] = __popcll(m);
+      if (k == kk) rank = __popcll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (k >= 0) {
+      int pre = 0;
+      for (int w = 0; w < wave; ++w) pre += wtot[w][k];
+      rows[start[k] + run[k] + pre + rank] = b;
+    }
+    __syncthreads();
+    if (tid < K) run[tid] += (wtot[0][tid] + wtot[1][tid]) + (wtot[2][tid] + wtot[3][tid]);
+    __syncthreads();
+  }
+}
+
+Buckets no_buckets() { return Buckets{1, nullptr, nullptr, nullptr, nullptr, 0}; }
+
+// host-side check + conversion of the C struct; K == 1 -> the reference path whatever the pointers say
+int buckets_from(const nnue_buckets* c, int B, Buckets* out, const char* who) {
+  *out = no_buckets();
+  if (!c || c->K <= 1) return NNUE_OK;
+  NNUE_REQUIRE(c->K <= kMaxBuckets, NNUE_E_SHAPE, "%s: %d layer stacks (at most %d)", who, c->K, kMaxBuckets);
+  NNUE_REQUIRE(c->bucket && c->rows && c->tile_bucket && c->seg, NNUE_E_ARG, "%s: null bucket pointer", who);
+  NNUE_REQUIRE(c->tiles == bucket_tiles(B, c->K), NNUE_E_SHAPE, "%s: bucket grouping was made for another batch (tiles %d, expected %d)", who,
+               c->tiles, bucket_tiles(B, c->K));
+  *out = Buckets{c->K, c->bucket, c->rows, c->tile_bucket, c->seg, c->tiles};
+  return NNUE_OK;
 }
 
 }  // namespace
 
 // =============================================================================== C ABI
-extern "C" int64_t nnue_classifier_scratch(int B, int L1, int L2, int L3) {
-  if (B <= 0 || L1 <= 0 || L2 <= 0 || L3 <= 0) return 0;
-  const ClsPlan a = make_plan(B, L1, L2, 0), b = make_plan(B, L1, L2, 1);
-  const int64_t fa = plan_scratch_floats(a, B, L1, L2, L3), fb = plan_scratch_floats(b, B, L1, L2, L3);
-  return (fa > fb ? fa : fb) * (int64_t)sizeof(float);
-}
+namespace {
 
-extern "C" int nnue_classifier_forward(const float* x, int pairwise, const float* w1, const float* b1, const float* w2,
-                                       const float* b2, const float* w3, const float* b3, float clip, int B, int L1,
-                                       int L2, int L3, int C, float* h1, float* h2, float* logits, void* scratch,
-                                       int64_t scratch_bytes, nnue_stream_t stream) {
+int forward_impl(const float* x, int pairwise, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                 const float* b3, float clip, int B, int L1, int L2, int L3, int C, float* h1, float* h2, float* logits, void* scratch,
+                 int64_t scratch_bytes, const Buckets& bk, nnue_stream_t stream) {
   NNUE_REQUIRE(x && w1 && b1 && w2 && b2 && w3 && b3 && h1 && h2 && logits && scratch, NNUE_E_ARG,
                "nnue_classifier_forward: null pointer");
   NNUE_REQUIRE(B > 0 && L1 > 0 && L2 > 0 && L3 > 0 && C > 0, NNUE_E_ARG,
                "nnue_classifier_forward: B=%d L1=%d L2=%d L3=%d C=%d must be positive", B, L1, L2, L3, C);
   NNUE_REQUIRE(!pairwise || L1 % 2 == 0, NNUE_E_SHAPE, "nnue_classifier_forward: pairwise needs an even L1 (got %d)", L1);
   NNUE_REQUIRE((int64_t)(L2 + L3) * 4 <= 64 * 1024, NNUE_E_SHAPE, "nnue_classifier_forward: L2+L3 too large for the LDS tail");
-  const ClsPlan p = make_plan(B, L1, L2, pairwise);
-  NNUE_REQUIRE(scratch_bytes >= plan_scratch_floats(p, B, L1, L2, L3) * (int64_t)sizeof(float), NNUE_E_SCRATCH,
+  const ClsPlan p = make_plan(B, L1, L2, pairwise, bk.K);
+  NNUE_REQUIRE(scratch_bytes >= plan_scratch_floats(p, B, L1, L2, L3, bk.K) * (int64_t)sizeof(float), NNUE_E_SCRATCH,
                "nnue_classifier_forward: scratch %lld bytes too small", (long long)scratch_bytes);
   NNUE_REQUIRE(nnue_aligned16(x) && nnue_aligned16(w1) && nnue_aligned16(scratch), NNUE_E_ARG,
                "nnue_classifier_forward: pointers must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* part = static_cast<float*>(scratch);
+  const int m_tiles = bk.rows ? bk.tiles : (B + 15) / 16;
   if (p.fwd_mfma) {
-    const long long waves = (long long)((B + 15) / 16) * ((L2 + 63) / 64) * p.fwd_ksplit;
+    const long long waves = (long long)m_tiles * ((L2 + 63) / 64) * p.fwd_ksplit;
     hipLaunchKernelGGL(l1_forward_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, B, L1, L2,
-                       p.fwd_ksplit, part);
+                       p.fwd_ksplit, part, bk);
   } else {
     const long long waves = (long long)B * L2;
-    hipLaunchKernelGGL(l1_forward_simple, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, B, L1, L2, part);
+    hipLaunchKernelGGL(l1_forward_simple, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, B, L1, L2, part, bk);
   }
   hipLaunchKernelGGL(tail_forward_kernel, dim3(B), dim3(128), (size_t)(L2 + L3) * sizeof(float), s, part, p.fwd_ksplit, b1,
-                     w2, b2, w3, b3, clip, B, L2, L3, C, h1, h2, logits);
+                     w2, b2, w3, b3, clip, B, L2, L3, C, h1, h2, logits, bk);
   return nnue_launch_status("nnue_classifier_forward");
+}
+
+int backward_impl(const float* x, int pairwise, const float* w1, const float* w2, const float* w3, float clip, const float* h1,
+                  const float* h2, const float* d_logits, int B, int L1, int L2, int L3, int C, float* d_x, float* d_w1, float* d_b1,
+                  float* d_w2, float* d_b2, float* d_w3, float* d_b3, void* scratch, int64_t scratch_bytes, const Buckets& bk,
+                  nnue_stream_t stream) {
+  NNUE_REQUIRE(x && w1 && w2 && w3 && h1 && h2 && d_logits && scratch, NNUE_E_ARG, "nnue_classifier_backward: null input pointer");
+  NNUE_REQUIRE(d_w1 && d_b1 && d_w2 && d_b2 && d_w3 && d_b3, NNUE_E_ARG, "nnue_classifier_backward: null gradient pointer");
+  NNUE_REQUIRE(B > 0 && L1 > 0 && L2 > 0 && L3 > 0 && C > 0, NNUE_E_ARG,
+               "nnue_classifier_backward: B=%d L1=%d L2=%d L3=%d C=%d must be positive", B, L1, L2, L3, C);
+  NNUE_REQUIRE(!pairwise || L1 % 2 == 0, NNUE_E_SHAPE, "nnue_classifier_backward: pairwise needs an even L1 (got %d)", L1);
+  NNUE_REQUIRE((int64_t)(C + L3) * 4 <= 64 * 1024, NNUE_E_SHAPE, "nnue_classifier_backward: C+L3 too large for the LDS tail");
+  const ClsPlan p = make_plan(B, L1, L2, pairwise, bk.K);
+  NNUE_REQUIRE(scratch_bytes >= plan_scratch_floats(p, B, L1, L2, L3, bk.K) * (int64_t)sizeof(float), NNUE_E_SCRATCH,
+               "nnue_classifier_backward: scratch %lld bytes too small", (long long)scratch_bytes);
+  NNUE_REQUIRE(nnue_aligned16(x) && nnue_aligned16(w1) && nnue_aligned16(scratch) && nnue_aligned16(d_w1), NNUE_E_ARG,
+               "nnue_classifier_backward: pointers must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int K = bk.K;
+  const int m_tiles = bk.rows ? bk.tiles : (B + 15) / 16;
+  float* d_z1 = static_cast<float*>(scratch);
+  float* d_z2 = d_z1 + nnue_round_up((int64_t)B * L2, 4);
+  float* slabs = d_z2 + nnue_round_up((int64_t)B * L3, 4);
+  hipLaunchKernelGGL(tail_backward_kernel, dim3(B), dim3(128), (size_t)(C + L3) * sizeof(float), s, d_logits, h1, h2, w2, w3,
+                     clip, L2, L3, C, d_z1, d_z2, bk);
+  {
+    const long long outs = K * ((long long)C * (L3 % 4 == 0 ? L3 / 4 : L3) + (long long)L3 * (L2 % 4 == 0 ? L2 / 4 : L2) + C + L3 + L2);
+    const SmallWgrad a{d_logits, d_z2, d_z1, h1, h2, B, L2, L3, C, d_w3, d_b3, d_w2, d_b2, d_b1, nullptr, nullptr, (int)((outs + 3) / 4),
+                       nullptr, 0, 0ll, nullptr, bk, p.bww_klen};
+    hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, s, a);
+  }
+  if (p.bww_mfma) {
+    const long long waves = (long long)K * (L2 / 32) * (L1 / 64) * p.bww_ksplit;
+    float* target = p.bww_ksplit > 1 ? slabs : d_w1;
+    hipLaunchKernelGGL(l1_backward_w_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, d_z1, B, L1, L2,
+                       p.bww_ksplit, p.bww_klen, target, bk);
+    if (p.bww_ksplit > 1) {
+      const long long count = (long long)K * L2 * L1;
+      hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, s, slabs, p.bww_ksplit,
+                         count, d_w1, bk, p.bww_klen);
+    }
+  } else {
+    hipLaunchKernelGGL(l1_backward_w_simple, dim3(K * L2, (L1 + 255) / 256), dim3(256), 0, s, x, pairwise, d_z1, B, L1, L2, d_w1, bk);
+  }
+  if (d_x) {
+    if (p.bwx_mfma) {
+      const long long waves = (long long)m_tiles * (L1 / 32);
+      hipLaunchKernelGGL(l1_backward_x_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1,
+                         L2, d_x, bk);
+    } else {
+      const int cols = pairwise ? L1 / 2 : L1;
+      hipLaunchKernelGGL(l1_backward_x_simple, dim3(B, (cols + 255) / 256), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1, L2,
+                         d_x, bk);
+    }
+  }
+  return nnue_launch_status("nnue_classifier_backward");
+}
+
+}  // namespace
+
+extern "C" int64_t nnue_classifier_scratch(int B, int L1, int L2, int L3) { return nnue_classifier_scratch_bucketed(B, L1, L2, L3, 1); }
+
+extern "C" int64_t nnue_classifier_scratch_bucketed(int B, int L1, int L2, int L3, int K) {
+  if (B <= 0 || L1 <= 0 || L2 <= 0 || L3 <= 0 || K <= 0) return 0;
+  const ClsPlan a = make_plan(B, L1, L2, 0, K), b = make_plan(B, L1, L2, 1, K);
+  const int64_t fa = plan_scratch_floats(a, B, L1, L2, L3, K), fb = plan_scratch_floats(b, B, L1, L2, L3, K);
+  return (fa > fb ? fa : fb) * (int64_t)sizeof(float);
+}
+
+extern "C" int nnue_bucket_tile_count(int B, int K) { return (B > 0 && K > 0) ? bucket_tiles(B, K) : 0; }
+
+extern "C" int nnue_bucket_group(const int32_t* n, int B, int P, int K, int32_t* bucket, int32_t* rows, int32_t* tile_bucket,
+                                 int32_t* seg, nnue_stream_t stream) {
+  NNUE_REQUIRE(n && bucket && rows && tile_bucket && seg, NNUE_E_ARG, "nnue_bucket_group: null pointer");
+  NNUE_REQUIRE(B > 0 && P >= 0 && K >= 1, NNUE_E_ARG, "nnue_bucket_group: B=%d P=%d K=%d out of range", B, P, K);
+  NNUE_REQUIRE(K <= kMaxBuckets, NNUE_E_SHAPE, "nnue_bucket_group: %d layer stacks (at most %d)", K, kMaxBuckets);
+  hipLaunchKernelGGL(bucket_group_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), n, B, P, K, bucket, rows, tile_bucket,
+                     seg, bucket_tiles(B, K));
+  return nnue_launch_status("nnue_bucket_group");
+}
+
+extern "C" int nnue_classifier_forward(const float* x, int pairwise, const float* w1, const float* b1, const float* w2,
+                                       const float* b2, const float* w3, const float* b3, float clip, int B, int L1,
+                                       int L2, int L3, int C, float* h1, float* h2, float* logits, void* scratch,
+                                       int64_t scratch_bytes, nnue_stream_t stream) {
+  return forward_impl(x, pairwise, w1, b1, w2, b2, w3, b3, clip, B, L1, L2, L3, C, h1, h2, logits, scratch, scratch_bytes, no_buckets(),
+                      stream);
+}
+
+extern "C" int nnue_classifier_forward_bucketed(const float* x, int pairwise, const float* w1, const float* b1, const float* w2,
+                                                const float* b2, const float* w3, const float* b3, float clip, int B, int L1, int L2,
+                                                int L3, int C, float* h1, float* h2, float* logits, void* scratch,
+                                                int64_t scratch_bytes, const nnue_buckets* buckets, nnue_stream_t stream) {
+  Buckets bk;
+  const int rc = buckets_from(buckets, B, &bk, "nnue_classifier_forward_bucketed");
+  if (rc != NNUE_OK) return rc;
+  return forward_impl(x, pairwise, w1, b1, w2, b2, w3, b3, clip, B, L1, L2, L3, C, h1, h2, logits, scratch, scratch_bytes, bk, stream);
 }
 
 extern "C" int nnue_classifier_backward(const float* x, int pairwise, const float* w1, const float* w2, const float* w3,
@@ -820,54 +1105,20 @@ extern "C" int nnue_classifier_backward(const float* x, int pairwise, const floa
                                         int L2, int L3, int C, float* d_x, float* d_w1, float* d_b1, float* d_w2,
                                         float* d_b2, float* d_w3, float* d_b3, void* scratch, int64_t scratch_bytes,
                                         nnue_stream_t stream) {
-  NNUE_REQUIRE(x && w1 && w2 && w3 && h1 && h2 && d_logits && scratch, NNUE_E_ARG, "nnue_classifier_backward: null input pointer");
-  NNUE_REQUIRE(d_w1 && d_b1 && d_w2 && d_b2 && d_w3 && d_b3, NNUE_E_ARG, "nnue_classifier_backward: null gradient pointer");
-  NNUE_REQUIRE(B > 0 && L1 > 0 && L2 > 0 && L3 > 0 && C > 0, NNUE_E_ARG,
-               "nnue_classifier_backward: B=%d L1=%d L2=%d L3=%d C=%d must be positive", B, L1, L2, L3, C);
-  NNUE_REQUIRE(!pairwise || L1 % 2 == 0, NNUE_E_SHAPE, "nnue_classifier_backward: pairwise needs an even L1 (got %d)", L1);
-  NNUE_REQUIRE((int64_t)(C + L3) * 4 <= 64 * 1024, NNUE_E_SHAPE, "nnue_classifier_backward: C+L3 too large for the LDS tail");
-  const ClsPlan p = make_plan(B, L1, L2, pairwise);
-  NNUE_REQUIRE(scratch_bytes >= plan_scratch_floats(p, B, L1, L2, L3) * (int64_t)sizeof(float), NNUE_E_SCRATCH,
-               "nnue_classifier_backward: scratch %lld bytes too small", (long long)scratch_bytes);
-  NNUE_REQUIRE(nnue_aligned16(x) && nnue_aligned16(w1) && nnue_aligned16(scratch) && nnue_aligned16(d_w1), NNUE_E_ARG,
-               "nnue_classifier_backward: pointers must be 16-byte aligned");
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  float* d_z1 = static_cast<float*>(scratch);
-  float* d_z2 = d_z1 + nnue_round_up((int64_t)B * L2, 4);
-  float* slabs = d_z2 + nnue_round_up((int64_t)B * L3, 4);
-  hipLaunchKernelGGL(tail_backward_kernel, dim3(B), dim3(128), (size_t)(C + L3) * sizeof(float), s, d_logits, h1, h2, w2, w3,
-                     clip, L2, L3, C, d_z1, d_z2);
-  {
-    const long long outs = (long long)C * (L3 % 4 == 0 ? L3 / 4 : L3) + (long long)L3 * (L2 % 4 == 0 ? L2 / 4 : L2) + C + L3 + L2;
-    const SmallWgrad a{d_logits, d_z2, d_z1, h1, h2, B, L2, L3, C, d_w3, d_b3, d_w2, d_b2, d_b1, nullptr, nullptr, (int)((outs + 3) / 4),
-                       nullptr, 0, 0ll, nullptr};
-    hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, s, a);
-  }
-  if (p.bww_mfma) {
-    const long long waves = (long long)(L2 / 32) * (L1 / 64) * p.bww_ksplit;
-    float* target = p.bww_ksplit > 1 ? slabs : d_w1;
-    hipLaunchKernelGGL(l1_backward_w_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, d_z1, B, L1, L2,
-                       p.bww_ksplit, p.bww_klen, target);
-    if (p.bww_ksplit > 1) {
-      const long long count = (long long)L2 * L1;
-      hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, s, slabs, p.bww_ksplit,
-                         count, d_w1);
-    }
-  } else {
-    hipLaunchKernelGGL(l1_backward_w_simple, dim3(L2, (L1 + 255) / 256), dim3(256), 0, s, x, pairwise, d_z1, B, L1, L2, d_w1);
-  }
-  if (d_x) {
-    if (p.bwx_mfma) {
-      const long long waves = (long long)((B + 15) / 16) * (L1 / 32);
-      hipLaunchKernelGGL(l1_backward_x_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1,
-                         L2, d_x);
-    } else {
-      const int cols = pairwise ? L1 / 2 : L1;
-      hipLaunchKernelGGL(l1_backward_x_simple, dim3(B, (cols + 255) / 256), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1, L2,
-                         d_x);
-    }
-  }
-  return nnue_launch_status("nnue_classifier_backward");
+  return backward_impl(x, pairwise, w1, w2, w3, clip, h1, h2, d_logits, B, L1, L2, L3, C, d_x, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, scratch,
+                       scratch_bytes, no_buckets(), stream);
+}
+
+extern "C" int nnue_classifier_backward_bucketed(const float* x, int pairwise, const float* w1, const float* w2, const float* w3,
+                                                 float clip, const float* h1, const float* h2, const float* d_logits, int B, int L1,
+                                                 int L2, int L3, int C, float* d_x, float* d_w1, float* d_b1, float* d_w2, float* d_b2,
+                                                 float* d_w3, float* d_b3, void* scratch, int64_t scratch_bytes,
+                                                 const nnue_buckets* buckets, nnue_stream_t stream) {
+  Buckets bk;
+  const int rc = buckets_from(buckets, B, &bk, "nnue_classifier_backward_bucketed");
+  if (rc != NNUE_OK) return rc;
+  return backward_impl(x, pairwise, w1, w2, w3, clip, h1, h2, d_logits, B, L1, L2, L3, C, d_x, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, scratch,
+                       scratch_bytes, bk, stream);
 }
 
 // d_x and the small weight/bias gradients + mean loss in one launch: both only read what the per-sample tail kernel
@@ -875,7 +1126,7 @@ extern "C" int nnue_classifier_backward(const float* x, int pairwise, const floa
 __global__ __launch_bounds__(256) void l1_backward_x_small_wgrad(const float* __restrict__ x, int pairwise, const float* __restrict__ w1,
                                                                  const float* __restrict__ d_z1, int B, int L1, int L2,
                                                                  float* __restrict__ d_x, int x_blocks, SmallWgrad a) {
-  if ((int)blockIdx.x < x_blocks) l1_backward_x_body(x, pairwise, w1, d_z1, B, L1, L2, d_x, blockIdx.x);
+  if ((int)blockIdx.x < x_blocks) l1_backward_x_body(x, pairwise, w1, d_z1, B, L1, L2, d_x, blockIdx.x, a.bk);
   else small_wgrad_body(a, (int)blockIdx.x - x_blocks);
 }
 
@@ -884,7 +1135,7 @@ namespace {
 struct TrainLayout {
   int64_t part, d_z1, d_z2, d_logits, slabs, total;  // float offsets
 };
-TrainLayout train_layout(const ClsPlan& p, int B, int L1, int L2, int L3, int C) {
+TrainLayout train_layout(const ClsPlan& p, int B, int L1, int L2, int L3, int C, int K = 1) {
   TrainLayout t{};
   int64_t off = 0;
   auto take = [&](int64_t n) { const int64_t o = off; off += nnue_round_up(n, 4); return o; };
@@ -895,16 +1146,121 @@ TrainLayout train_layout(const ClsPlan& p, int B, int L1, int L2, int L3, int C)
   t.d_z1 = take((int64_t)B * L2);
   t.d_z2 = take((int64_t)B * L3);
   t.d_logits = take((int64_t)B * C);
-  t.slabs = take(p.bww_ksplit > 1 ? (int64_t)p.bww_ksplit * L2 * L1 : 0);
+  t.slabs = take(p.bww_ksplit > 1 ? (int64_t)p.bww_ksplit * K * L2 * L1 : 0);
   t.total = off + 4;
   return t;
+}
+
+int train_step_impl(const float* x, int pairwise, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                    const float* b3, float clip, const int64_t* labels, float grad_scale, int B, int L1, int L2, int L3, int C, float* h1,
+                    float* h2, float* logits, float* sample_loss, float* loss, float* d_x, float* d_w1, float* d_b1, float* d_w2,
+                    float* d_b2, float* d_w3, float* d_b3, void* scratch, int64_t scratch_bytes, int phases, const Buckets& bk,
+                    nnue_stream_t stream) {
+  NNUE_REQUIRE(x && w1 && b1 && w2 && b2 && w3 && b3 && labels && h1 && h2 && logits && sample_loss && loss && scratch,
+               NNUE_E_ARG, "nnue_classifier_train_step: null pointer");
+  NNUE_REQUIRE(phases >= 1 && phases <= 31 && (phases & 3) && (phases & 20) != 20, NNUE_E_ARG,
+               "nnue_classifier_train_step: phases = 1 (activations + d_x) | 2 (weight gradients + loss) [| 4: first-layer weight product beside "
+               "d_x] [| 8: layer-1 slabs already at the start of scratch] [| 16 (not with 4): d_w1 comes from nnue_ftm_backward]");
+  const bool ext_dw1 = (phases & 16) != 0;
+  const bool ext_slabs = (phases & 8) != 0;
+  const int K = bk.K;
+  NNUE_REQUIRE(K == 1 || !(ext_dw1 || ext_slabs), NNUE_E_ARG,
+               "nnue_classifier_train_step: phases bits 8 / 16 (products formed inside the FeatureTransformer launches) exist for one layer stack only");
+  NNUE_REQUIRE(!ext_slabs || (pairwise && L1 % 64 == 0), NNUE_E_SHAPE,
+               "nnue_classifier_train_step: phases bit 8 needs the pairwise block and L1 %% 64 == 0 (got L1=%d)", L1);
+  NNUE_REQUIRE(d_w1 && d_b1 && d_w2 && d_b2 && d_w3 && d_b3, NNUE_E_ARG, "nnue_classifier_train_step: null gradient pointer");
+  NNUE_REQUIRE(B > 0 && L1 > 0 && L2 > 0 && L3 > 0 && C > 0, NNUE_E_ARG,
+               "nnue_classifier_train_step: B=%d L1=%d L2=%d L3=%d C=%d must be positive", B, L1, L2, L3, C);
+  NNUE_REQUIRE(!pairwise || L1 % 2 == 0, NNUE_E_SHAPE, "nnue_classifier_train_step: pairwise needs an even L1 (got %d)", L1);
+  const int64_t tail_lds = ((int64_t)L2 + 2 * L3 + C + 8) * 4;
+  NNUE_REQUIRE(tail_lds <= 64 * 1024, NNUE_E_SHAPE, "nnue_classifier_train_step: L2+2*L3+C too large for the LDS tail");
+  const ClsPlan p = make_plan(B, L1, L2, pairwise, K);
+  const TrainLayout t = train_layout(p, B, L1, L2, L3, C, K);
+  NNUE_REQUIRE(scratch_bytes >= t.total * (int64_t)sizeof(float), NNUE_E_SCRATCH,
+               "nnue_classifier_train_step: scratch %lld < %lld bytes", (long long)scratch_bytes, (long long)(t.total * 4));
+  NNUE_REQUIRE(nnue_aligned16(x) && nnue_aligned16(w1) && nnue_aligned16(scratch) && nnue_aligned16(d_w1) && nnue_aligned16(h1) &&
+                   nnue_aligned16(h2),
+               NNUE_E_ARG, "nnue_classifier_train_step: pointers must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* base = static_cast<float*>(scratch);
+  float *part = base + t.part, *d_z1 = base + t.d_z1, *d_z2 = base + t.d_z2, *d_logits = base + t.d_logits, *slabs = base + t.slabs;
+  const bool slab_pass = p.bww_mfma && p.bww_ksplit > 1;
+  const int m_tiles = bk.rows ? bk.tiles : (B + 15) / 16;
+  // bit 4: the d_w1 product runs in phase 1's d_x launch (both MFMA forms, d_x requested); a later phase-2 call with the
+  // same bit then only sums its slabs
+  const bool early_bww = (phases & 4) && p.bwx_mfma && p.bww_mfma && d_x != nullptr;
+  const int tail_slabs = ext_slabs ? L1 / 64 : p.fwd_ksplit;
+  // one launch: the small weight/bias gradients (per layer stack), the mean loss and (piggy-backed) the d_w1 slab sum
+  const long long outs = K * ((long long)C * (L3 % 4 == 0 ? L3 / 4 : L3) + (long long)L3 * (L2 % 4 == 0 ? L2 / 4 : L2) + C + L3 + L2) + 1;
+  const int wgrad_blocks = (int)((outs + 3) / 4);
+  const long long count = (long long)K * L2 * L1;
+  const int slab_blocks = slab_pass && !ext_dw1 ? (int)((count / 4 + 255) / 256) : 0;
+  const SmallWgrad sw{d_logits, d_z2, d_z1, h1, h2, B, L2, L3, C, d_w3, d_b3, d_w2, d_b2, d_b1, sample_loss, loss, wgrad_blocks,
+                      slabs, slab_pass && !ext_dw1 ? p.bww_ksplit : 0, count, d_w1, bk, p.bww_klen};
+  // both phases in one call with d_w1 left to nnue_ftm_backward: the small gradients ride in the d_x launch
+  const bool wgrad_rides = (phases & 3) == 3 && ext_dw1 && p.bwx_mfma && d_x != nullptr;
+  if (phases & 1) {
+    if (ext_slabs) {
+      // part[L1/64][B][L2] was written by nnue_ftm_forward_l1 (the FeatureTransformer forward's epilogue)
+    } else if (p.fwd_mfma) {
+      const long long waves = (long long)m_tiles * ((L2 + 63) / 64) * p.fwd_ksplit;
+      hipLaunchKernelGGL(l1_forward_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, B, L1, L2, p.fwd_ksplit, part, bk);
+    } else {
+      const long long waves = (long long)B * L2;
+      hipLaunchKernelGGL(l1_forward_simple, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, B, L1, L2, part, bk);
+    }
+    const bool vec = L2 % 4 == 0 && L3 % 4 == 0 && nnue_aligned16(w2) && nnue_aligned16(w3);
+#define NNUE_TAIL(NT, V)                                                                                                                  \
+  hipLaunchKernelGGL((tail_train_kernel<NT, V>), dim3(B), dim3(NT), (size_t)tail_lds, s, part, tail_slabs, b1, w2, b2, w3, b3, clip, labels, \
+                     grad_scale / (float)B, B, L2, L3, C, h1, h2, logits, sample_loss, d_logits, d_z1, d_z2, bk)
+    if (C > 256) { if (vec) NNUE_TAIL(512, true); else NNUE_TAIL(512, false); }
+    else { if (vec) NNUE_TAIL(128, true); else NNUE_TAIL(128, false); }
+#undef NNUE_TAIL
+    if (d_x) {
+      if (p.bwx_mfma && early_bww) {
+        const long long xw = (long long)m_tiles * (L1 / 32), ww = (long long)K * (L2 / 32) * (L1 / 64) * p.bww_ksplit;
+        const int w_blocks = (int)((ww + 3) / 4);
+        hipLaunchKernelGGL(l1_backward_xw_mfma, dim3((unsigned)(w_blocks + (xw + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1, L2,
+                           d_x, w_blocks, p.bww_ksplit, p.bww_klen, slab_pass ? slabs : d_w1, bk);
+      } else if (wgrad_rides) {
+        const long long waves = (long long)m_tiles * (L1 / 32);
+        const int x_blocks = (int)((waves + 3) / 4);
+        hipLaunchKernelGGL(l1_backward_x_small_wgrad, dim3((unsigned)(x_blocks + wgrad_blocks)), dim3(256), 0, s, x, pairwise, w1,
+                           (const float*)d_z1, B, L1, L2, d_x, x_blocks, sw);
+      } else if (p.bwx_mfma) {
+        const long long waves = (long long)m_tiles * (L1 / 32);
+        hipLaunchKernelGGL(l1_backward_x_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1, L2, d_x, bk);
+      } else {
+        const int cols = pairwise ? L1 / 2 : L1;
+        hipLaunchKernelGGL(l1_backward_x_simple, dim3(B, (cols + 255) / 256), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1, L2, d_x, bk);
+      }
+    }
+  }
+  if (wgrad_rides) return nnue_launch_status("nnue_classifier_train_step");
+  if (phases & 2) {  // needs phase 1's h1, h2, d_logits, d_z1, d_z2 (scratch) -- nothing downstream depends on it
+    if (early_bww || ext_dw1) {
+      // the first-layer product already ran beside d_x (phases bit 4), or rides in nnue_ftm_backward's launch (bit 16)
+    } else if (p.bww_mfma) {
+      const long long waves = (long long)K * (L2 / 32) * (L1 / 64) * p.bww_ksplit;
+      hipLaunchKernelGGL(l1_backward_w_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, d_z1, B, L1, L2, p.bww_ksplit,
+                         p.bww_klen, slab_pass ? slabs : d_w1, bk);
+    } else {
+      hipLaunchKernelGGL(l1_backward_w_simple, dim3(K * L2, (L1 + 255) / 256), dim3(256), 0, s, x, pairwise, d_z1, B, L1, L2, d_w1, bk);
+    }
+    hipLaunchKernelGGL(small_wgrad_kernel, dim3(wgrad_blocks + slab_blocks), dim3(256), 0, s, sw);
+  }
+  return nnue_launch_status("nnue_classifier_train_step");
 }
 }  // namespace
 
 extern "C" int64_t nnue_classifier_train_scratch(int B, int L1, int L2, int L3, int C) {
-  if (B <= 0 || L1 <= 0 || L2 <= 0 || L3 <= 0 || C <= 0) return 0;
-  const int64_t a = train_layout(make_plan(B, L1, L2, 0), B, L1, L2, L3, C).total;
-  const int64_t b = train_layout(make_plan(B, L1, L2, 1), B, L1, L2, L3, C).total;
+  return nnue_classifier_train_scratch_bucketed(B, L1, L2, L3, C, 1);
+}
+
+extern "C" int64_t nnue_classifier_train_scratch_bucketed(int B, int L1, int L2, int L3, int C, int K) {
+  if (B <= 0 || L1 <= 0 || L2 <= 0 || L3 <= 0 || C <= 0 || K <= 0) return 0;
+  const int64_t a = train_layout(make_plan(B, L1, L2, 0, K), B, L1, L2, L3, C, K).total;
+  const int64_t b = train_layout(make_plan(B, L1, L2, 1, K), B, L1, L2, L3, C, K).total;
   return (a > b ? a : b) * (int64_t)sizeof(float);
 }
 
@@ -919,95 +1275,19 @@ extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const fl
                                           float* h1, float* h2, float* logits, float* sample_loss, float* loss, float* d_x,
                                           float* d_w1, float* d_b1, float* d_w2, float* d_b2, float* d_w3, float* d_b3,
                                           void* scratch, int64_t scratch_bytes, int phases, nnue_stream_t stream) {
-  NNUE_REQUIRE(x && w1 && b1 && w2 && b2 && w3 && b3 && labels && h1 && h2 && logits && sample_loss && loss && scratch,
-               NNUE_E_ARG, "nnue_classifier_train_step: null pointer");
-  NNUE_REQUIRE(phases >= 1 && phases <= 31 && (phases & 3) && (phases & 20) != 20, NNUE_E_ARG,
-               "nnue_classifier_train_step: phases = 1 (activations + d_x) | 2 (weight gradients + loss) [| 4: first-layer weight product beside "
-               "d_x] [| 8: layer-1 slabs already at the start of scratch] [| 16 (not with 4): d_w1 comes from nnue_ftm_backward]");
-  const bool ext_dw1 = (phases & 16) != 0;
-  const bool ext_slabs = (phases & 8) != 0;
-  NNUE_REQUIRE(!ext_slabs || (pairwise && L1 % 64 == 0), NNUE_E_SHAPE,
-               "nnue_classifier_train_step: phases bit 8 needs the pairwise block and L1 %% 64 == 0 (got L1=%d)", L1);
-  NNUE_REQUIRE(d_w1 && d_b1 && d_w2 && d_b2 && d_w3 && d_b3, NNUE_E_ARG, "nnue_classifier_train_step: null gradient pointer");
-  NNUE_REQUIRE(B > 0 && L1 > 0 && L2 > 0 && L3 > 0 && C > 0, NNUE_E_ARG,
-               "nnue_classifier_train_step: B=%d L1=%d L2=%d L3=%d C=%d must be positive", B, L1, L2, L3, C);
-  NNUE_REQUIRE(!pairwise || L1 % 2 == 0, NNUE_E_SHAPE, "nnue_classifier_train_step: pairwise needs an even L1 (got %d)", L1);
-  const int64_t tail_lds = ((int64_t)L2 + 2 * L3 + C + 8) * 4;
-  NNUE_REQUIRE(tail_lds <= 64 * 1024, NNUE_E_SHAPE, "nnue_classifier_train_step: L2+2*L3+C too large for the LDS tail");
-  const ClsPlan p = make_plan(B, L1, L2, pairwise);
-  const TrainLayout t = train_layout(p, B, L1, L2, L3, C);
-  NNUE_REQUIRE(scratch_bytes >= t.total * (int64_t)sizeof(float), NNUE_E_SCRATCH,
-               "nnue_classifier_train_step: scratch %lld < %lld bytes", (long long)scratch_bytes, (long long)(t.total * 4));
-  NNUE_REQUIRE(nnue_aligned16(x) && nnue_aligned16(w1) && nnue_aligned16(scratch) && nnue_aligned16(d_w1) && nnue_aligned16(h1) &&
-                   nnue_aligned16(h2),
-               NNUE_E_ARG, "nnue_classifier_train_step: pointers must be 16-byte aligned");
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  float* base = static_cast<float*>(scratch);
-  float *part = base + t.part, *d_z1 = base + t.d_z1, *d_z2 = base + t.d_z2, *d_logits = base + t.d_logits, *slabs = base + t.slabs;
-  const bool slab_pass = p.bww_mfma && p.bww_ksplit > 1;
-  // bit 4: the d_w1 product runs in phase 1's d_x launch (both MFMA forms, d_x requested); a later phase-2 call with the
-  // same bit then only sums its slabs
-  const bool early_bww = (phases & 4) && p.bwx_mfma && p.bww_mfma && d_x != nullptr;
-  const int tail_slabs = ext_slabs ? L1 / 64 : p.fwd_ksplit;
-  // one launch: the small weight/bias gradients, the mean loss and (piggy-backed) the d_w1 slab sum
-  const long long outs = (long long)C * (L3 % 4 == 0 ? L3 / 4 : L3) + (long long)L3 * (L2 % 4 == 0 ? L2 / 4 : L2) + C + L3 + L2 + 1;
-  const int wgrad_blocks = (int)((outs + 3) / 4);
-  const long long count = (long long)L2 * L1;
-  const int slab_blocks = slab_pass && !ext_dw1 ? (int)((count / 4 + 255) / 256) : 0;
-  const SmallWgrad sw{d_logits, d_z2, d_z1, h1, h2, B, L2, L3, C, d_w3, d_b3, d_w2, d_b2, d_b1, sample_loss, loss, wgrad_blocks,
-                      slabs, slab_pass && !ext_dw1 ? p.bww_ksplit : 0, count, d_w1};
-  // both phases in one call with d_w1 left to nnue_ftm_backward: the small gradients ride in the d_x launch
-  const bool wgrad_rides = (phases & 3) == 3 && ext_dw1 && p.bwx_mfma && d_x != nullptr;
-  if (phases & 1) {
-    if (ext_slabs) {
-      // part[L1/64][B][L2] was written by nnue_ftm_forward_l1 (the FeatureTransformer forward's epilogue)
-    } else if (p.fwd_mfma) {
-      const long long waves = (long long)((B + 15) / 16) * ((L2 + 63) / 64) * p.fwd_ksplit;
-      hipLaunchKernelGGL(l1_forward_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, B, L1, L2, p.fwd_ksplit, part);
-    } else {
-      const long long waves = (long long)B * L2;
-      hipLaunchKernelGGL(l1_forward_simple, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, B, L1, L2, part);
-    }
-    const bool vec = L2 % 4 == 0 && L3 % 4 == 0 && nnue_aligned16(w2) && nnue_aligned16(w3);
-#define NNUE_TAIL(NT, V)                                                                                                                  \
-  hipLaunchKernelGGL((tail_train_kernel<NT, V>), dim3(B), dim3(NT), (size_t)tail_lds, s, part, tail_slabs, b1, w2, b2, w3, b3, clip, labels, \
-                     grad_scale / (float)B, B, L2, L3, C, h1, h2, logits, sample_loss, d_logits, d_z1, d_z2)
-    if (C > 256) { if (vec) NNUE_TAIL(512, true); else NNUE_TAIL(512, false); }
-    else { if (vec) NNUE_TAIL(128, true); else NNUE_TAIL(128, false); }
-#undef NNUE_TAIL
-    if (d_x) {
-      if (p.bwx_mfma && early_bww) {
-        const long long xw = (long long)((B + 15) / 16) * (L1 / 32), ww = (long long)(L2 / 32) * (L1 / 64) * p.bww_ksplit;
-        const int w_blocks = (int)((ww + 3) / 4);
-        hipLaunchKernelGGL(l1_backward_xw_mfma, dim3((unsigned)(w_blocks + (xw + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1, L2,
-                           d_x, w_blocks, p.bww_ksplit, p.bww_klen, slab_pass ? slabs : d_w1);
-      } else if (wgrad_rides) {
-        const long long waves = (long long)((B + 15) / 16) * (L1 / 32);
-        const int x_blocks = (int)((waves + 3) / 4);
-        hipLaunchKernelGGL(l1_backward_x_small_wgrad, dim3((unsigned)(x_blocks + wgrad_blocks)), dim3(256), 0, s, x, pairwise, w1,
-                           (const float*)d_z1, B, L1, L2, d_x, x_blocks, sw);
-      } else if (p.bwx_mfma) {
-        const long long waves = (long long)((B + 15) / 16) * (L1 / 32);
-        hipLaunchKernelGGL(l1_backward_x_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1, L2, d_x);
-      } else {
-        const int cols = pairwise ? L1 / 2 : L1;
-        hipLaunchKernelGGL(l1_backward_x_simple, dim3(B, (cols + 255) / 256), dim3(256), 0, s, x, pairwise, w1, d_z1, B, L1, L2, d_x);
-      }
-    }
-  }
-  if (wgrad_rides) return nnue_launch_status("nnue_classifier_train_step");
-  if (phases & 2) {  // needs phase 1's h1, h2, d_logits, d_z1, d_z2 (scratch) -- nothing downstream depends on it
-    if (early_bww || ext_dw1) {
-      // the first-layer product already ran beside d_x (phases bit 4), or rides in nnue_ftm_backward's launch (bit 16)
-    } else if (p.bww_mfma) {
-      const long long waves = (long long)(L2 / 32) * (L1 / 64) * p.bww_ksplit;
-      hipLaunchKernelGGL(l1_backward_w_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, pairwise, d_z1, B, L1, L2, p.bww_ksplit,
-                         p.bww_klen, slab_pass ? slabs : d_w1);
-    } else {
-      hipLaunchKernelGGL(l1_backward_w_simple, dim3(L2, (L1 + 255) / 256), dim3(256), 0, s, x, pairwise, d_z1, B, L1, L2, d_w1);
-    }
-    hipLaunchKernelGGL(small_wgrad_kernel, dim3(wgrad_blocks + slab_blocks), dim3(256), 0, s, sw);
-  }
-  return nnue_launch_status("nnue_classifier_train_step");
+  return train_step_impl(x, pairwise, w1, b1, w2, b2, w3, b3, clip, labels, grad_scale, B, L1, L2, L3, C, h1, h2, logits, sample_loss, loss,
+                         d_x, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, scratch, scratch_bytes, phases, no_buckets(), stream);
 }
 
+extern "C" int nnue_classifier_train_step_bucketed(const float* x, int pairwise, const float* w1, const float* b1, const float* w2,
+                                                   const float* b2, const float* w3, const float* b3, float clip, const int64_t* labels,
+                                                   float grad_scale, int B, int L1, int L2, int L3, int C, float* h1, float* h2,
+                                                   float* logits, float* sample_loss, float* loss, float* d_x, float* d_w1, float* d_b1,
+                                                   float* d_w2, float* d_b2, float* d_w3, float* d_b3, void* scratch,
+                                                   int64_t scratch_bytes, int phases, const nnue_buckets* buckets, nnue_stream_t stream) {
+  Buckets bk;
+  const int rc = buckets_from(buckets, B, &bk, "nnue_classifier_train_step_bucketed");
+  if (rc != NNUE_OK) return rc;
+  return train_step_impl(x, pairwise, w1, b1, w2, b2, w3, b3, clip, labels, grad_scale, B, L1, L2, L3, C, h1, h2, logits, sample_loss, loss,
+                         d_x, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, scratch, scratch_bytes, phases, bk, stream);
+}

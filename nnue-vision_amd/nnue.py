@@ -123,24 +123,82 @@ class SimpleClassifier(nn.Module):
         a, b, c = self._linears()
         lead = x.shape[:-1]
         y = _ops.ClassifierFn.apply(x.reshape(-1, x.shape[-1]), a.weight, a.bias, b.weight, b.bias, c.weight, c.bias,
-                                    False, float(self.clip_activations or 0.0))
+                                    False, float(self.clip_activations or 0.0), None)
         return y.reshape(*lead, y.shape[-1])
+
+
+class BucketedLinear(nn.Module):
+    """K independent Linear layers stacked to weight [K, out, in] / bias [K, out]; slice k is initialised exactly like
+    ``nn.Linear(in, out)`` (the draws happen bucket by bucket).  Build extension -- the reference has one stack."""
+
+    def __init__(self, num_buckets: int, in_features: int, out_features: int):
+        super().__init__()
+        self.num_buckets, self.in_features, self.out_features = num_buckets, in_features, out_features
+        stacks = [nn.Linear(in_features, out_features) for _ in range(num_buckets)]
+        self.weight = nn.Parameter(torch.stack([m.weight.detach() for m in stacks]))
+        self.bias = nn.Parameter(torch.stack([m.bias.detach() for m in stacks]))
+
+    def stack(self, k: int) -> nn.Linear:
+        """Bucket k as a stock nn.Linear (a copy: for export / inspection)."""
+        m = nn.Linear(self.in_features, self.out_features)
+        with torch.no_grad():
+            m.weight.copy_(self.weight[k])
+            m.bias.copy_(self.bias[k])
+        return m
+
+    def extra_repr(self) -> str:
+        return f"buckets={self.num_buckets}, in_features={self.in_features}, out_features={self.out_features}"
+
+
+class BucketedClassifier(nn.Module):
+    """``num_ls_buckets`` SimpleClassifier weight sets, one selected per sample (BASELINE configs[2]:
+    the engine's LayerStack vector, engine/src/nnue_engine.cpp:619-635, brought back to training).  Same attribute and
+    state-dict key names as SimpleClassifier (``classifier.{0,2,4}.{weight,bias}``), the tensors carry a leading K."""
+
+    def __init__(self, l1_size: int, l2_size: int, l3_size: int, num_classes: int, num_buckets: int):
+        super().__init__()
+        self.num_classes, self.num_buckets = num_classes, num_buckets
+        self.classifier = nn.Sequential(
+            BucketedLinear(num_buckets, l1_size, l2_size),
+            nn.ReLU(),
+            BucketedLinear(num_buckets, l2_size, l3_size),
+            nn.ReLU(),
+            BucketedLinear(num_buckets, l3_size, num_classes),
+        )
+        self.clip_activations: Optional[float] = None
+
+    def _linears(self):
+        seq = self.classifier
+        return seq[0], seq[2], seq[4]
+
+    def forward(self, x: torch.Tensor, bucket: torch.Tensor) -> torch.Tensor:
+        """x [B, L1] (the pairwise block's output), bucket integer [B] in [0, K): the stack of each sample."""
+        a, b, c = self._linears()
+        return _ops.ClassifierFn.apply(x.reshape(-1, x.shape[-1]), a.weight, a.bias, b.weight, b.bias, c.weight, c.bias,
+                                       False, float(self.clip_activations or 0.0), bucket.reshape(-1))
+
+
+def bucket_of(active_counts: torch.Tensor, num_buckets: int, flat_ids: int) -> torch.Tensor:
+    """The selector: min(K-1, n*K // (flat_ids+1)) with n the sample's active-feature count and flat_ids = fps*Gh*Gw
+    of the map it was counted on.  NNUE.forward computes it on the device from the binarise
+    kernel's counts; this is the same rule for callers that drive the stand-alone modules."""
+    return torch.clamp((active_counts.long() * num_buckets) // (flat_ids + 1), max=num_buckets - 1)
 
 
 class NNUE(nn.Module):
     """NNUE image classifier (nnue.py:447-671): 3x3 conv -> per-channel threshold -> active grid
     features -> FeatureTransformer -> pairwise product -> SimpleClassifier.
 
-    Two keyword extensions with reference-preserving defaults:
-    ``num_ls_buckets`` (only 1 is implemented) and ``clip_activations`` (None = plain ReLU)."""
+    Two keyword extensions with reference-preserving defaults: ``num_ls_buckets`` (1 = the reference's
+    SimpleClassifier, bit for bit; K > 1 = BucketedClassifier) and ``clip_activations`` (None = plain ReLU)."""
 
     def __init__(self, feature_set: Optional[GridFeatureSet] = None, l1_size: int = DEFAULT_L1,
                  l2_size: int = DEFAULT_L2, l3_size: int = DEFAULT_L3, loss_params=LossParams(), num_classes=1,
                  weight_decay=5e-4, input_size=32, num_ls_buckets: int = 1,
                  clip_activations: Optional[float] = None):
         super().__init__()
-        if num_ls_buckets != 1:
-            raise NotImplementedError("num_ls_buckets > 1 is a planned extension; the reference has exactly one stack")
+        if not 1 <= int(num_ls_buckets) <= 64:
+            raise ValueError("num_ls_buckets must be in 1..64")
         if l1_size % 2:
             raise ValueError("l1_size must be even (pairwise product splits it in two)")
         if feature_set is None:
@@ -157,7 +215,8 @@ class NNUE(nn.Module):
         # creation order == the reference's, so torch.manual_seed(s); NNUE(...) draws identical weights
         self.conv = nn.Conv2d(3, fps, kernel_size=3, stride=stride, padding=1, bias=False)
         self.input = FeatureTransformer(feature_set.num_features, l1_size)
-        self.classifier = SimpleClassifier(l1_size, l2_size, l3_size, num_classes)
+        self.classifier = (SimpleClassifier(l1_size, l2_size, l3_size, num_classes) if num_ls_buckets == 1 else
+                           BucketedClassifier(l1_size, l2_size, l3_size, num_classes, num_ls_buckets))
         self.classifier.clip_activations = clip_activations
         self.nnue2score = nn.Parameter(torch.tensor(600.0))
         self.visual_threshold = nn.Parameter(torch.full((fps,), 0.1))
@@ -197,7 +256,7 @@ class NNUE(nn.Module):
         with torch.no_grad():
             self.input.weight.clamp_(-1.0, 1.0)
             for m in self.classifier.modules():
-                if isinstance(m, nn.Linear):
+                if isinstance(m, (nn.Linear, BucketedLinear)):
                     m.weight.clamp_(-1.0, 1.0)
 
     def get_quantized_model_data(self):
@@ -217,12 +276,19 @@ class NNUE(nn.Module):
             "quantized_one": 127.0,
             "visual_threshold": float(self.visual_threshold.detach().mean().cpu().item()),
         }
-        layers = [quantize_linear_layer(m) for m in self.classifier.classifier if isinstance(m, nn.Linear)]
+        if self.num_ls_buckets == 1:
+            layers = [quantize_linear_layer(m) for m in self.classifier.classifier if isinstance(m, nn.Linear)]
+            classifier = {"layers": layers}
+        else:  # one record per layer stack, bucket order (what engine/src/nnue_engine.cpp:619-635 reads back)
+            meta["num_ls_buckets"] = self.num_ls_buckets
+            stacks = [{"layers": [quantize_linear_layer(m.stack(k)) for m in self.classifier._linears()]}
+                      for k in range(self.num_ls_buckets)]
+            classifier = {"layers": stacks[0]["layers"], "stacks": stacks}
         return {
             "metadata": meta,
             "conv_layer": quantize_conv_layer(self.conv),
             "feature_transformer": quantize_linear_layer(self.input),
-            "classifier": {"layers": layers},
+            "classifier": classifier,
         }
 
 

@@ -42,7 +42,10 @@ class EvalPlan:
         self.acts = (torch.empty((batch, l2), **f32), torch.empty((batch, l3), **f32), torch.empty((batch, c), **f32))
         self.logits = self.acts[2]
         self.ce = (torch.empty((batch,), **f32), torch.zeros((), **f32), None)
-        self.cls_scratch = torch.empty((lib.classifier_scratch_bytes(batch, l1, l2, l3),), dtype=torch.uint8, device=self.dev)
+        self.K = int(getattr(model, "num_ls_buckets", 1))
+        self.positions = fps * gh * gw
+        self.bucket_plan = lib.BucketPlan(batch, self.K, self.dev) if self.K > 1 else None
+        self.cls_scratch = torch.empty((lib.classifier_scratch_bytes(batch, l1, l2, l3, self.K),), dtype=torch.uint8, device=self.dev)
         k = 2 if c == 1 else c
         self.classes = c
         self.confusion = torch.zeros((k, k), dtype=torch.int64, device=self.dev)
@@ -76,7 +79,10 @@ class EvalPlan:
             lib.conv3x3_forward(self.images, conv_w, self.stride, out=self.conv_out)
             lib.binarize_features(self.conv_out, thr, self.num_rows, act=self.feats)
             lib.ft_forward(ft_w, ft_b, self.feats, out=self.ft)
-        lib.classifier_forward(self.ft, True, w1, b1, w2, b2, w3, b3, self.clip, scratch=self.cls_scratch, out=self.acts)
+        if self.bucket_plan is not None:
+            lib.bucket_group(self.feats.n, self.positions, self.K, plan=self.bucket_plan)
+        lib.classifier_forward(self.ft, True, w1, b1, w2, b2, w3, b3, self.clip, scratch=self.cls_scratch, out=self.acts,
+                               buckets=self.bucket_plan)
         lib.cross_entropy(self.logits, self.labels, want_grad=False, out=self.ce)
         self.loss_sum.add_(self.ce[1].double())
         if self.classes == 1:  # the reference's binary rule for the metrics (evaluate.py:30-37)

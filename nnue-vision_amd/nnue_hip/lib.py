@@ -16,9 +16,18 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+
+class NnueBuckets(ctypes.Structure):
+    """struct nnue_buckets of include/nnue_hip.h (read on the host by the *_bucketed entry points)."""
+    _fields_ = [("K", ctypes.c_int32), ("bucket", _c_p), ("rows", _c_p), ("tile_bucket", _c_p), ("seg", _c_p),
+                ("tiles", ctypes.c_int32)]
+
+
+_c_bk = ctypes.POINTER(NnueBuckets)
 
 # name -> (restype, argtypes); mirrors include/nnue_hip.h one to one
 SIGNATURES = {
@@ -75,6 +84,20 @@ SIGNATURES = {
                                             _c_int, _c_int, _c_int, _c_int, _c_int,
                                             _c_p, _c_p, _c_p, _c_p, _c_p,
                                             _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
+    "nnue_bucket_tile_count": (_c_int, [_c_int, _c_int]),
+    "nnue_bucket_group": (_c_int, [_c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p]),
+    "nnue_classifier_scratch_bucketed": (_c_i64, [_c_int, _c_int, _c_int, _c_int, _c_int]),
+    "nnue_classifier_train_scratch_bucketed": (_c_i64, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
+    "nnue_classifier_forward_bucketed": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_f,
+                                                  _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p,
+                                                  _c_p, _c_i64, _c_bk, _c_p]),
+    "nnue_classifier_backward_bucketed": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p, _c_f, _c_p, _c_p, _c_p,
+                                                   _c_int, _c_int, _c_int, _c_int, _c_int,
+                                                   _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_bk, _c_p]),
+    "nnue_classifier_train_step_bucketed": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_f, _c_p, _c_f,
+                                                     _c_int, _c_int, _c_int, _c_int, _c_int,
+                                                     _c_p, _c_p, _c_p, _c_p, _c_p,
+                                                     _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_int, _c_bk, _c_p]),
     "nnue_cross_entropy": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_f, _c_p, _c_p, _c_p, _c_p]),
     "nnue_confusion_accumulate": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_p, _c_p]),
     "nnue_load_batch": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_i64, _c_int, ctypes.c_uint64, ctypes.c_uint64,
@@ -701,67 +724,119 @@ def ftm_backward(d_out: torch.Tensor, weight: torch.Tensor, fm: FeatureMatrix, d
     return d_weight, d_bias, dst
 
 
+# ---------------------------------------------------------------------------- bucketed layer stacks
+class BucketPlan:
+    """Per-batch bucket assignment + grouping (struct nnue_buckets): which of the K layer stacks each sample uses and
+    the bucket-homogeneous 16-row tiles the first-layer MFMA kernels walk.  Buffers are static (hipGraph-friendly);
+    ``bucket_group`` refills them from the active-feature counts of a batch."""
+
+    def __init__(self, batch: int, buckets: int, device):
+        self.batch, self.K = int(batch), int(buckets)
+        self.tiles = int(load().nnue_bucket_tile_count(self.batch, self.K))
+        i32 = dict(dtype=torch.int32, device=device)
+        self.bucket = torch.zeros((self.batch,), **i32)
+        self.rows = torch.full((self.tiles * 16,), -1, **i32)
+        self.tile_bucket = torch.full((self.tiles,), -1, **i32)
+        self.seg = torch.zeros((self.K + 1,), **i32)
+        self.cstruct = NnueBuckets(self.K, self.bucket.data_ptr(), self.rows.data_ptr(), self.tile_bucket.data_ptr(),
+                                   self.seg.data_ptr(), self.tiles)
+
+    @property
+    def ref(self):
+        return ctypes.byref(self.cstruct)
+
+
+def bucket_group(n: torch.Tensor, positions: int, buckets: int, plan: Optional[BucketPlan] = None) -> BucketPlan:
+    """bucket[b] = min(K-1, n[b]*K // (positions+1)) and the grouping; positions == 0: n holds the bucket ids themselves."""
+    n = _need(n, torch.int32, "active-feature counts")
+    b = n.numel()
+    if plan is None:
+        plan = BucketPlan(b, buckets, n.device)
+    elif plan.batch != b or plan.K != buckets:
+        raise ValueError("bucket_group: plan was built for another batch size / bucket count")
+    _call("nnue_bucket_group", n.data_ptr(), b, int(positions), int(buckets), plan.bucket.data_ptr(), plan.rows.data_ptr(),
+          plan.tile_bucket.data_ptr(), plan.seg.data_ptr(), _stream(n))
+    return plan
+
+
 # ---------------------------------------------------------------------------- classifier
-def classifier_scratch_bytes(b: int, l1: int, l2: int, l3: int) -> int:
-    return int(load().nnue_classifier_scratch(b, l1, l2, l3))
+def classifier_scratch_bytes(b: int, l1: int, l2: int, l3: int, buckets: int = 1) -> int:
+    return int(load().nnue_classifier_scratch_bucketed(b, l1, l2, l3, buckets))
+
+
+def _cls_shapes(w1, b1, w2, b2, w3, b3, l1: int, buckets: Optional[BucketPlan]):
+    """Checks the six (possibly stacked) tensors; returns them contiguous with (l2, l3, c, K)."""
+    k = buckets.K if buckets is not None else 1
+    lead = (k,) if w1.dim() == 3 else ()
+    if (w1.dim() == 3) != (buckets is not None) or (lead and w1.shape[0] != k):
+        raise ValueError("stacked [K, out, in] classifier weights need a BucketPlan with the same K (and vice versa)")
+    l2, l3, c = w1.shape[-2], w2.shape[-2], w3.shape[-2]
+    w1 = _need(w1, torch.float32, "classifier.0.weight", (*lead, l2, l1))
+    w2 = _need(w2, torch.float32, "classifier.2.weight", (*lead, l3, l2))
+    w3 = _need(w3, torch.float32, "classifier.4.weight", (*lead, c, l3))
+    if b1 is not None:
+        b1 = _need(b1, torch.float32, "classifier.0.bias", (*lead, l2))
+        b2 = _need(b2, torch.float32, "classifier.2.bias", (*lead, l3))
+        b3 = _need(b3, torch.float32, "classifier.4.bias", (*lead, c))
+    return w1, b1, w2, b2, w3, b3, l2, l3, c, k
 
 
 def classifier_forward(x, pairwise: bool, w1, b1, w2, b2, w3, b3, clip: float = 0.0,
-                       scratch: Optional[torch.Tensor] = None, out=None):
+                       scratch: Optional[torch.Tensor] = None, out=None, buckets: Optional[BucketPlan] = None):
     x = _need(x, torch.float32, "classifier input")
     if x.dim() != 2:
         raise ValueError(f"classifier input: expected [B,L1], got {tuple(x.shape)}")
     b, l1 = x.shape
-    l2, l3, c = w1.shape[0], w2.shape[0], w3.shape[0]
-    w1 = _need(w1, torch.float32, "classifier.0.weight", (l2, l1))
-    b1 = _need(b1, torch.float32, "classifier.0.bias", (l2,))
-    w2 = _need(w2, torch.float32, "classifier.2.weight", (l3, l2))
-    b2 = _need(b2, torch.float32, "classifier.2.bias", (l3,))
-    w3 = _need(w3, torch.float32, "classifier.4.weight", (c, l3))
-    b3 = _need(b3, torch.float32, "classifier.4.bias", (c,))
+    w1, b1, w2, b2, w3, b3, l2, l3, c, k = _cls_shapes(w1, b1, w2, b2, w3, b3, l1, buckets)
     dev = x.device
     if scratch is None:
-        scratch = torch.empty((classifier_scratch_bytes(b, l1, l2, l3),), dtype=torch.uint8, device=dev)
+        scratch = torch.empty((classifier_scratch_bytes(b, l1, l2, l3, k),), dtype=torch.uint8, device=dev)
     if out is None:
         h1 = torch.empty((b, l2), dtype=torch.float32, device=dev)
         h2 = torch.empty((b, l3), dtype=torch.float32, device=dev)
         logits = torch.empty((b, c), dtype=torch.float32, device=dev)
     else:
         h1, h2, logits = out
-    _call("nnue_classifier_forward", x.data_ptr(), int(bool(pairwise)), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
-          b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), float(clip), b, l1, l2, l3, c, h1.data_ptr(), h2.data_ptr(),
-          logits.data_ptr(), scratch.data_ptr(), scratch.numel(), _stream(x))
+    args = (x.data_ptr(), int(bool(pairwise)), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+            b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), float(clip), b, l1, l2, l3, c, h1.data_ptr(), h2.data_ptr(),
+            logits.data_ptr(), scratch.data_ptr(), scratch.numel())
+    if buckets is None:
+        _call("nnue_classifier_forward", *args, _stream(x))
+    else:
+        _call("nnue_classifier_forward_bucketed", *args, buckets.ref, _stream(x))
     return h1, h2, logits
 
 
 def classifier_backward(x, pairwise: bool, w1, w2, w3, h1, h2, d_logits, clip: float = 0.0,
-                        want_dx: bool = True, scratch: Optional[torch.Tensor] = None, grads=None, d_x=None):
+                        want_dx: bool = True, scratch: Optional[torch.Tensor] = None, grads=None, d_x=None,
+                        buckets: Optional[BucketPlan] = None):
     x = _need(x, torch.float32, "classifier input")
     b, l1 = x.shape
-    l2, l3, c = w1.shape[0], w2.shape[0], w3.shape[0]
-    w1 = _need(w1, torch.float32, "classifier.0.weight", (l2, l1))
-    w2 = _need(w2, torch.float32, "classifier.2.weight", (l3, l2))
-    w3 = _need(w3, torch.float32, "classifier.4.weight", (c, l3))
+    w1, _, w2, _, w3, _, l2, l3, c, k = _cls_shapes(w1, None, w2, None, w3, None, l1, buckets)
     h1 = _need(h1, torch.float32, "h1", (b, l2))
     h2 = _need(h2, torch.float32, "h2", (b, l3))
     d_logits = _need(d_logits, torch.float32, "d_logits", (b, c))
     dev = x.device
+    lead = (k,) if buckets is not None else ()
     if scratch is None:
-        scratch = torch.empty((classifier_scratch_bytes(b, l1, l2, l3),), dtype=torch.uint8, device=dev)
+        scratch = torch.empty((classifier_scratch_bytes(b, l1, l2, l3, k),), dtype=torch.uint8, device=dev)
     if grads is None:
-        mk = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+        mk = lambda *s: torch.empty((*lead, *s), dtype=torch.float32, device=dev)  # noqa: E731
         grads = (mk(l2, l1), mk(l2), mk(l3, l2), mk(l3), mk(c, l3), mk(c))
     if want_dx and d_x is None:
         d_x = torch.empty((b, l1), dtype=torch.float32, device=dev)
-    _call("nnue_classifier_backward", x.data_ptr(), int(bool(pairwise)), w1.data_ptr(), w2.data_ptr(), w3.data_ptr(),
-          float(clip), h1.data_ptr(), h2.data_ptr(), d_logits.data_ptr(), b, l1, l2, l3, c,
-          _ptr(d_x if want_dx else None), *[g.data_ptr() for g in grads], scratch.data_ptr(), scratch.numel(),
-          _stream(x))
+    args = (x.data_ptr(), int(bool(pairwise)), w1.data_ptr(), w2.data_ptr(), w3.data_ptr(),
+            float(clip), h1.data_ptr(), h2.data_ptr(), d_logits.data_ptr(), b, l1, l2, l3, c,
+            _ptr(d_x if want_dx else None), *[g.data_ptr() for g in grads], scratch.data_ptr(), scratch.numel())
+    if buckets is None:
+        _call("nnue_classifier_backward", *args, _stream(x))
+    else:
+        _call("nnue_classifier_backward_bucketed", *args, buckets.ref, _stream(x))
     return (d_x if want_dx else None), grads
 
 
-def classifier_train_scratch_bytes(b: int, l1: int, l2: int, l3: int, c: int) -> int:
-    return int(load().nnue_classifier_train_scratch(b, l1, l2, l3, c))
+def classifier_train_scratch_bytes(b: int, l1: int, l2: int, l3: int, c: int, buckets: int = 1) -> int:
+    return int(load().nnue_classifier_train_scratch_bucketed(b, l1, l2, l3, c, buckets))
 
 
 def classifier_train_dz1_offset(b: int, l1: int, l2: int, l3: int, c: int, pairwise: bool) -> int:
@@ -771,34 +846,32 @@ def classifier_train_dz1_offset(b: int, l1: int, l2: int, l3: int, c: int, pairw
 
 def classifier_train_step(x, pairwise: bool, w1, b1, w2, b2, w3, b3, labels, grad_scale: float = 1.0, clip: float = 0.0,
                           want_dx: bool = True, scratch: Optional[torch.Tensor] = None, out=None, loss_out=None,
-                          grads=None, d_x=None, phases: int = 3):
+                          grads=None, d_x=None, phases: int = 3, buckets: Optional[BucketPlan] = None):
     """Forward + mean cross-entropy + backward of the classifier block in one C call.
     Returns (h1, h2, logits), (sample_loss, loss), d_x, grads."""
     x = _need(x, torch.float32, "classifier input")
     b, l1 = x.shape
-    l2, l3, c = w1.shape[0], w2.shape[0], w3.shape[0]
-    w1 = _need(w1, torch.float32, "classifier.0.weight", (l2, l1))
-    b1 = _need(b1, torch.float32, "classifier.0.bias", (l2,))
-    w2 = _need(w2, torch.float32, "classifier.2.weight", (l3, l2))
-    b2 = _need(b2, torch.float32, "classifier.2.bias", (l3,))
-    w3 = _need(w3, torch.float32, "classifier.4.weight", (c, l3))
-    b3 = _need(b3, torch.float32, "classifier.4.bias", (c,))
+    w1, b1, w2, b2, w3, b3, l2, l3, c, k = _cls_shapes(w1, b1, w2, b2, w3, b3, l1, buckets)
     labels = _need(labels, torch.int64, "labels", (b,))
     dev = x.device
+    lead = (k,) if buckets is not None else ()
     mk = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
     if scratch is None:
-        scratch = torch.empty((classifier_train_scratch_bytes(b, l1, l2, l3, c),), dtype=torch.uint8, device=dev)
+        scratch = torch.empty((classifier_train_scratch_bytes(b, l1, l2, l3, c, k),), dtype=torch.uint8, device=dev)
     h1, h2, logits = out if out is not None else (mk(b, l2), mk(b, l3), mk(b, c))
     sample_loss, loss = loss_out if loss_out is not None else (mk(b), mk())
     if grads is None:
-        grads = (mk(l2, l1), mk(l2), mk(l3, l2), mk(l3), mk(c, l3), mk(c))
+        grads = (mk(*lead, l2, l1), mk(*lead, l2), mk(*lead, l3, l2), mk(*lead, l3), mk(*lead, c, l3), mk(*lead, c))
     if want_dx and d_x is None:
         d_x = mk(b, l1)
-    _call("nnue_classifier_train_step", x.data_ptr(), int(bool(pairwise)), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
-          b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), float(clip), labels.data_ptr(), float(grad_scale), b, l1, l2, l3, c,
-          h1.data_ptr(), h2.data_ptr(), logits.data_ptr(), sample_loss.data_ptr(), loss.data_ptr(),
-          _ptr(d_x if want_dx else None), *[g.data_ptr() for g in grads], scratch.data_ptr(), scratch.numel(), int(phases),
-          _stream(x))
+    args = (x.data_ptr(), int(bool(pairwise)), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+            b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), float(clip), labels.data_ptr(), float(grad_scale), b, l1, l2, l3, c,
+            h1.data_ptr(), h2.data_ptr(), logits.data_ptr(), sample_loss.data_ptr(), loss.data_ptr(),
+            _ptr(d_x if want_dx else None), *[g.data_ptr() for g in grads], scratch.data_ptr(), scratch.numel(), int(phases))
+    if buckets is None:
+        _call("nnue_classifier_train_step", *args, _stream(x))
+    else:
+        _call("nnue_classifier_train_step_bucketed", *args, buckets.ref, _stream(x))
     return (h1, h2, logits), (sample_loss, loss), (d_x if want_dx else None), grads
 
 

@@ -40,11 +40,19 @@ class FeatureTransformerFn(torch.autograd.Function):
 
 
 class ClassifierFn(torch.autograd.Function):
+    """SimpleClassifier / BucketedClassifier.  ``bucket`` (integer [B], stacked weights only) names each sample's layer
+    stack; it is grouped on the device (nnue_bucket_group with P = 0)."""
+
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, w3, b3, pairwise, clip):
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, pairwise, clip, bucket=None):
         x = x.contiguous()
-        h1, h2, logits = lib.classifier_forward(x, pairwise, w1, b1, w2, b2, w3, b3, clip)
-        ctx.pairwise, ctx.clip = pairwise, clip
+        plan = None
+        if w1.dim() == 3:
+            if bucket is None:
+                raise ValueError("stacked classifier weights need the per-sample bucket ids")
+            plan = lib.bucket_group(bucket.to(device=x.device, dtype=torch.int32).contiguous(), 0, w1.shape[0])
+        h1, h2, logits = lib.classifier_forward(x, pairwise, w1, b1, w2, b2, w3, b3, clip, buckets=plan)
+        ctx.pairwise, ctx.clip, ctx.plan = pairwise, clip, plan
         ctx.save_for_backward(x, w1, w2, w3, h1, h2)
         return logits
 
@@ -52,8 +60,8 @@ class ClassifierFn(torch.autograd.Function):
     def backward(ctx, d_logits):
         x, w1, w2, w3, h1, h2 = ctx.saved_tensors
         d_x, g = lib.classifier_backward(x, ctx.pairwise, w1, w2, w3, h1, h2, d_logits.contiguous(), ctx.clip,
-                                         want_dx=ctx.needs_input_grad[0])
-        return (d_x, *g, None, None)
+                                         want_dx=ctx.needs_input_grad[0], buckets=ctx.plan)
+        return (d_x, *g, None, None, None)
 
 
 class SparseValuesFn(torch.autograd.Function):
@@ -89,8 +97,10 @@ class NnueFn(torch.autograd.Function):
         else:
             feats = lib.binarize_features(conv_out, thr, ft_w.shape[0])
             ft = lib.ft_forward(ft_w, ft_b, feats)
-        h1, h2, logits = lib.classifier_forward(ft, True, w1, b1, w2, b2, w3, b3, clip)
-        ctx.feats, ctx.stride, ctx.clip = feats, stride, clip
+        # bucketed layer stacks: each sample's stack follows from its active-feature count, grouped on the device
+        plan = lib.bucket_group(feats.n, conv_out[0].numel(), w1.shape[0]) if w1.dim() == 3 else None
+        h1, h2, logits = lib.classifier_forward(ft, True, w1, b1, w2, b2, w3, b3, clip, buckets=plan)
+        ctx.feats, ctx.stride, ctx.clip, ctx.plan = feats, stride, clip, plan
         ctx.save_for_backward(images, thr, conv_w, conv_out, ft_w, ft, w1, w2, w3, h1, h2)
         return logits
 
@@ -99,7 +109,7 @@ class NnueFn(torch.autograd.Function):
         images, thr, conv_w, conv_out, ft_w, ft, w1, w2, w3, h1, h2 = ctx.saved_tensors
         feats = ctx.feats
         need = ctx.needs_input_grad
-        d_ft, g_cls = lib.classifier_backward(ft, True, w1, w2, w3, h1, h2, d_logits.contiguous(), ctx.clip)
+        d_ft, g_cls = lib.classifier_backward(ft, True, w1, w2, w3, h1, h2, d_logits.contiguous(), ctx.clip, buckets=ctx.plan)
         d_ftw = d_ftb = d_thr = d_conv_w = d_images = None
         if need[3] or need[4]:
             if ctx.path == "mfma":

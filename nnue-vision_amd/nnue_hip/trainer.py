@@ -132,6 +132,8 @@ class NnueTrainer:
         self.F, self.L1 = model.input.weight.shape
         lin = model.classifier._linears()
         self.L2, self.L3, self.C = lin[0].out_features, lin[1].out_features, lin[2].out_features
+        # bucketed layer stacks (BASELINE configs[2]): stacked [K, out, in] classifier parameters, one stack per sample
+        self.K = int(getattr(model, "num_ls_buckets", 1))
         self.clip = float(model.classifier.clip_activations or 0.0)
         self.gh, self.gw = lib.conv_out_hw(self.H, self.W, self.stride)
         self.P = self.fps * self.gh * self.gw
@@ -183,8 +185,9 @@ class NnueTrainer:
         self.d_conv_out = torch.empty((B, self.P), **f32)
         self.grad_norm = torch.zeros((), **f32)
         u8 = dict(dtype=torch.uint8, device=self.dev)
-        self.cls_scratch = torch.empty((max(lib.classifier_scratch_bytes(B, self.L1, self.L2, self.L3),
-                                            lib.classifier_train_scratch_bytes(B, self.L1, self.L2, self.L3, self.C)),), **u8)
+        self.cls_scratch = torch.empty((max(lib.classifier_scratch_bytes(B, self.L1, self.L2, self.L3, self.K),
+                                            lib.classifier_train_scratch_bytes(B, self.L1, self.L2, self.L3, self.C, self.K)),), **u8)
+        self.bucket_plan = lib.BucketPlan(B, self.K, self.dev) if self.K > 1 else None
         self.ste_scratch = torch.empty((max(16, lib.load().nnue_ste_conv_backward_scratch(B, self.fps, self.gh, self.gw)),), **u8)
         self.sgd_scratch = torch.empty((lib.sgd_scratch_bytes(self.layout.count),), **u8)
         # single rank + SGD: the second stage of the STE / conv-weight gradient sum rides in the optimizer's norm launch
@@ -195,7 +198,9 @@ class NnueTrainer:
         # single rank + SGD: the FT weight-gradient tiles leave their sums of squares, so the clip norm does not read
         # those rows of the flat gradient buffer again (268 MB at the 224x224 configuration)
         self.sq_partial, self.sq_range = None, None
-        self.fuse_l1 = (self.use_mfma and os.environ.get("NNUE_FUSE_L1", "1") != "0"
+        # K > 1: the first layer's weights differ per sample, so its product is the classifier's own grouped launch
+        # (bucket-homogeneous MFMA tiles) instead of the FeatureTransformer forward's epilogue / backward rider
+        self.fuse_l1 = (self.K == 1 and self.use_mfma and os.environ.get("NNUE_FUSE_L1", "1") != "0"
                         and lib.ftm_forward_l1_supported(B, self.F, self.P, self.L1, self.L2))
         self.steps_done = 0
         self.use_graph = use_graph
@@ -213,7 +218,7 @@ class NnueTrainer:
         self.merge_backward = not self.branch and os.environ.get("NNUE_FTM_SPLIT_BACKWARD", "0") != "1"
         # the classifier's first-layer weight gradient rides in the merged FeatureTransformer backward launch (a third
         # tile family reading d_z1 out of the classifier's scratch) where that launch is used
-        self.ride_dw1 = (self.use_mfma and self.merge_backward and os.environ.get("NNUE_FTM_RIDE_DW1", "1") != "0"
+        self.ride_dw1 = (self.K == 1 and self.use_mfma and self.merge_backward and os.environ.get("NNUE_FTM_RIDE_DW1", "1") != "0"
                          and lib.ftm_backward_cw_supported(B, self.F, self.P, self.L1, self.L2))
         n_sq = lib.ftm_backward_sq_count(B, self.F, self.P, self.L1) if (self.use_mfma and self.merge_backward) else 0
         if (n_sq > 0 and not self.dp.collectives and optimizer == "sgd" and os.environ.get("NNUE_NORM_PARTIALS", "1") != "0"):
@@ -271,7 +276,7 @@ class NnueTrainer:
         cls_grads = tuple(g[f"classifier.classifier.{i}.{n}"] for i in (0, 2, 4) for n in ("weight", "bias"))
         lib.classifier_train_step(self.ft, True, *self._cls_params(), self.labels, 1.0, self.clip, scratch=self.cls_scratch,
                                   out=(self.h1, self.h2, self.logits), loss_out=(self.sample_loss, self.loss),
-                                  grads=cls_grads, d_x=self.d_ft, phases=phases)
+                                  grads=cls_grads, d_x=self.d_ft, phases=phases, buckets=self.bucket_plan)
 
     def _segment(self, name: str) -> None:
         p, g = self.p, self.g
@@ -289,6 +294,9 @@ class NnueTrainer:
             if self.use_bits:
                 lib.binarize_bits(self.conv_out, p["visual_threshold"], self.F, self.L1, bits=self.bits, stages=2)
         elif name == "forward":
+            if self.bucket_plan is not None:  # stack of each sample from the counts the binarise kernel just wrote
+                feats = self.fm if self.use_mfma else self.bits if self.use_bits else self.act
+                lib.bucket_group(feats.n, self.P, self.K, plan=self.bucket_plan)
             if self.use_mfma and self.fuse_l1:
                 # the forward's epilogue also forms the classifier's layer-1 slabs (start of its scratch)
                 lib.ftm_forward_l1(p["input.weight"], p["input.bias"], self.fm, p["classifier.classifier.0.weight"], self.cls_scratch,

@@ -7,7 +7,7 @@ Host-side code (numpy + struct on CPU tensors); nothing here is on the training 
 File layout, little-endian (writer: reference serialize.py:30-63, :103-136, :394-491; reader:
 engine/src/nnue_engine.cpp:544-657):
 
-  header   "NNUE" | u32 2 | u32 F | u32 L1 | u32 L2 | u32 L3 | u32 buckets(=1) |
+  header   "NNUE" | u32 2 | u32 F | u32 L1 | u32 L2 | u32 L3 | u32 buckets (1 in the reference; K for the bucketed extension) |
            f32 nnue2score | f32 quantized_one | f32 visual_threshold(mean)
   conv     u32 0 | f32 scale | u32 oc, ic, kh, kw | i8[oc*ic*kh*kw] | u32 oc | i32[oc]
   FT       f32 scale | u32 F | u32 L1 | i16[F*L1] | u32 L1 | i32[L1]
@@ -129,7 +129,10 @@ def write_layer_stack(f: BinaryIO, classifier_data: Dict[str, Any]) -> None:
 
 
 def write_classifier(f: BinaryIO, classifier_data: Dict[str, Any]) -> None:
-    write_layer_stack(f, classifier_data)
+    """One LayerStack record per bucket, in bucket order (the reader loops over the header's num_ls_buckets:
+    engine/src/nnue_engine.cpp:619-635); the reference's own writer always has exactly one (serialize.py:57, :494-497)."""
+    for stack in classifier_data.get("stacks", [classifier_data]):
+        write_layer_stack(f, stack)
 
 
 def serialize_model(model: NNUE, output_path) -> None:
@@ -161,11 +164,17 @@ def infer_architecture_from_state_dict(state_dict) -> Tuple[GridFeatureSet, int,
                 grid, fps = g, c
                 break
     def rows(key, default):
-        return state_dict[key].shape[0] if key in state_dict else default
+        return state_dict[key].shape[-2] if key in state_dict else default  # [out, in] or stacked [K, out, in]
     l2 = rows("classifier.classifier.0.weight", 16)
     l3 = rows("classifier.classifier.2.weight", 32)
     classes = rows("classifier.classifier.4.weight", 10)
     return GridFeatureSet(grid, fps), l1, l2, l3, classes
+
+
+def num_ls_buckets_of(state_dict) -> int:
+    """1 for the reference's checkpoints; K for the bucketed extension (stacked [K, out, in] classifier weights)."""
+    w = state_dict.get("classifier.classifier.0.weight")
+    return int(w.shape[0]) if w is not None and w.dim() == 3 else 1
 
 
 def load_model_from_checkpoint(checkpoint_path) -> NNUE:
@@ -179,7 +188,8 @@ def load_model_from_checkpoint(checkpoint_path) -> NNUE:
         feature_set, l1, l2, l3, classes = saved
     else:
         feature_set, l1, l2, l3, classes = infer_architecture_from_state_dict(state)
-    model = NNUE(feature_set=feature_set, l1_size=l1, l2_size=l2, l3_size=l3, num_classes=classes)
+    model = NNUE(feature_set=feature_set, l1_size=l1, l2_size=l2, l3_size=l3, num_classes=classes,
+                 num_ls_buckets=num_ls_buckets_of(state))
     model.load_state_dict(state)
     return model
 

@@ -24,6 +24,16 @@ Two forms are kept on purpose:
 
 All arithmetic is float32 unless ``dtype=torch.float64`` is passed (used by the
 tests to measure how far float32 summation order can move a result).
+
+Bucketed layer stacks (``num_ls_buckets = K > 1``, BASELINE configs[2]) and the
+clipped-ReLU option are BUILD EXTENSIONS: the reference trains exactly one stack
+with plain ReLU (nnue.py:499-500, :728-734; serialize.py:57), so for them this
+file is the definition rather than a restatement -- **parity unpinned** (no
+reference output exists to pin against; K = 1 / clip None reduces to the pinned
+functions, which the tests check).  Definition:
+stacked weights ``[K, out, in]``, one stack per sample chosen by
+``bucket = min(K-1, n*K // (flat_ids+1))`` with ``n`` the sample's number of
+active features and ``flat_ids = fps*Gh*Gw``.
 """
 
 from __future__ import annotations
@@ -139,6 +149,35 @@ def classifier_forward(x, w1, b1, w2, b2, w3, b3, clip: Optional[float] = None):
     return F.linear(act(F.linear(act(F.linear(x, w1, b1)), w2, b2)), w3, b3)
 
 
+def bucket_index(n: torch.Tensor, buckets: int, flat_ids: int) -> torch.Tensor:
+    """Layer stack of each sample from its active-feature count (build extension): the
+    vision analogue of the piece-count buckets the engine's LayerStack vector descends from
+    (engine/src/nnue_engine.cpp:619-635)."""
+    return torch.clamp((n.long() * buckets) // (flat_ids + 1), max=buckets - 1)
+
+
+def classifier_forward_bucketed(x, bucket, w1, b1, w2, b2, w3, b3, clip: Optional[float] = None):
+    """classifier_forward with stacked weights [K, out, in]: sample b goes through stack bucket[b] (loop form)."""
+    rows = [classifier_forward(x[b:b + 1], w1[k], b1[k], w2[k], b2[k], w3[k], b3[k], clip)
+            for b, k in enumerate(bucket.tolist())]
+    return torch.cat(rows, dim=0)
+
+
+def classifier_backward_bucketed(x, bucket, w1, b1, w2, b2, w3, b3, d_logits, clip: Optional[float] = None):
+    """Closed-form backward of classifier_forward_bucketed: every stack sums over its own samples only."""
+    d_x = torch.zeros_like(x)
+    grads = [torch.zeros_like(t) for t in (w1, b1, w2, b2, w3, b3)]
+    for k in range(w1.shape[0]):
+        sel = (bucket == k).nonzero().squeeze(-1)
+        if sel.numel() == 0:
+            continue
+        dx_k, g_k = classifier_backward(x[sel], w1[k], b1[k], w2[k], b2[k], w3[k], b3[k], d_logits[sel], clip)
+        d_x[sel] = dx_k
+        for dst, g in zip(grads, g_k):
+            dst[k] = g
+    return d_x, grads
+
+
 PARAM_KEYS = (
     "nnue2score",
     "visual_threshold",
@@ -156,32 +195,34 @@ TRAINABLE_KEYS = PARAM_KEYS[1:]  # nnue2score never receives a gradient
 
 
 def model_forward_loop(p: Dict[str, torch.Tensor], images: torch.Tensor, stride: int,
-                       keep: Optional[dict] = None) -> torch.Tensor:
-    """NNUE.forward in the reference's loop form (nnue.py:637-671)."""
+                       keep: Optional[dict] = None, clip: Optional[float] = None) -> torch.Tensor:
+    """NNUE.forward in the reference's loop form (nnue.py:637-671).  Stacked classifier weights ([K, out, in]) select
+    the bucketed extension; ``clip`` the clipped-ReLU one."""
     x = conv_forward(images, p["conv.weight"], stride)
     bits = binarize(x, p["visual_threshold"])
     idx, val = to_sparse_features_loop(bits)
     ft = ft_forward_loop(p["input.weight"], p["input.bias"], idx, val)
-    logits = classifier_forward(
-        pairwise(ft),
-        p["classifier.classifier.0.weight"], p["classifier.classifier.0.bias"],
-        p["classifier.classifier.2.weight"], p["classifier.classifier.2.bias"],
-        p["classifier.classifier.4.weight"], p["classifier.classifier.4.bias"],
-    )
+    cls = [p[f"classifier.classifier.{i}.{n}"] for i in (0, 2, 4) for n in ("weight", "bias")]
+    if cls[0].dim() == 3:
+        bucket = bucket_index((idx >= 0).sum(dim=1), cls[0].shape[0], bits[0].numel())
+        logits = classifier_forward_bucketed(pairwise(ft), bucket, *cls, clip)
+    else:
+        bucket = None
+        logits = classifier_forward(pairwise(ft), *cls, clip)
     if keep is not None:
-        keep.update(conv_out=x, bits=bits, idx=idx, val=val, ft=ft)
+        keep.update(conv_out=x, bits=bits, idx=idx, val=val, ft=ft, bucket=bucket)
     return logits
 
 
-def loss_and_grads_loop(p: Dict[str, torch.Tensor], images, labels, stride: int):
+def loss_and_grads_loop(p: Dict[str, torch.Tensor], images, labels, stride: int, clip: Optional[float] = None):
     """compute_loss + backward (train.py:250-254, :360-361) through autograd."""
     q = {k: v.detach().clone().requires_grad_(k != "nnue2score") for k, v in p.items()}
     keep: dict = {}
-    logits = model_forward_loop(q, images, stride, keep)
+    logits = model_forward_loop(q, images, stride, keep, clip)
     loss = F.cross_entropy(logits, labels.long())
     loss.backward()
     grads = {k: q[k].grad for k in TRAINABLE_KEYS}
-    return logits.detach(), loss.detach(), grads, {k: v.detach() for k, v in keep.items()}
+    return logits.detach(), loss.detach(), grads, {k: v.detach() for k, v in keep.items() if v is not None}
 
 
 # --------------------------------------------------------------------------
@@ -296,7 +337,7 @@ def conv_weight_grad(images, d_conv_out, stride: int, kshape) -> torch.Tensor:
     return g
 
 
-def loss_and_grads_explicit(p: Dict[str, torch.Tensor], images, labels, stride: int):
+def loss_and_grads_explicit(p: Dict[str, torch.Tensor], images, labels, stride: int, clip: Optional[float] = None):
     """Whole step without autograd: the exact chain of products the HIP path runs.
 
     conv -> ids -> ft -> pairwise -> classifier -> CE, then back through
@@ -312,9 +353,16 @@ def loss_and_grads_explicit(p: Dict[str, torch.Tensor], images, labels, stride: 
     val = (idx >= 0).to(x.dtype)
     ft = ft_forward(w, b, idx, val)
     l0 = pairwise(ft)
-    logits = classifier_forward(l0, *cls)
-    loss, d_logits = cross_entropy_backward(logits, labels)
-    d_l0, d_cls = classifier_backward(l0, *cls, d_logits)
+    bucket = None
+    if cls[0].dim() == 3:  # bucketed layer stacks (build extension)
+        bucket = bucket_index(n, cls[0].shape[0], x[0].numel())
+        logits = classifier_forward_bucketed(l0, bucket, *cls, clip)
+        loss, d_logits = cross_entropy_backward(logits, labels)
+        d_l0, d_cls = classifier_backward_bucketed(l0, bucket, *cls, d_logits, clip)
+    else:
+        logits = classifier_forward(l0, *cls, clip)
+        loss, d_logits = cross_entropy_backward(logits, labels)
+        d_l0, d_cls = classifier_backward(l0, *cls, d_logits, clip)
     d_ft = pairwise_backward(ft, d_l0)
     d_w, d_b, d_val = ft_backward(w, idx, val, d_ft)
     # dval lands on the *unclamped* flat position of each active id; inactive positions get 0
@@ -336,7 +384,7 @@ def loss_and_grads_explicit(p: Dict[str, torch.Tensor], images, labels, stride: 
     }
     for k, g in zip(TRAINABLE_KEYS[4:], d_cls):
         grads[k] = g
-    keep_t = dict(conv_out=x, idx=idx, n=n, ft=ft, d_ft=d_ft, d_conv_out=d_x, d_logits=d_logits)
+    keep_t = dict(conv_out=x, idx=idx, n=n, ft=ft, d_ft=d_ft, d_conv_out=d_x, d_logits=d_logits, bucket=bucket)
     return logits, loss, grads, keep_t
 
 
@@ -402,13 +450,24 @@ def adam_step(params: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor], s
 # parameter initialisation in the reference's RNG order (nnue.py:486-507, :683-684, :728-734)
 # --------------------------------------------------------------------------
 def init_params(grid_size: int, fps: int, l1: int, l2: int, l3: int, num_classes: int,
-                seed: int) -> Dict[str, torch.Tensor]:
+                seed: int, buckets: int = 1) -> Dict[str, torch.Tensor]:
     """Draws parameters with the same generator calls, in the same order, as
-    ``torch.manual_seed(seed); NNUE(...)`` does in the reference."""
+    ``torch.manual_seed(seed); NNUE(...)`` does in the reference.  buckets > 1 (extension): every layer holds
+    ``buckets`` independent nn.Linear draws stacked to [K, out, in], layer by layer."""
     torch.manual_seed(seed)
     conv = torch.nn.Conv2d(3, fps, 3, stride=1, padding=1, bias=False)  # stride does not touch the RNG
     ft_w = torch.randn(num_features(grid_size, fps), l1) * 0.1
-    lin = [torch.nn.Linear(l1, l2), torch.nn.Linear(l2, l3), torch.nn.Linear(l3, num_classes)]
+
+    class _Stack:
+        def __init__(self, fan_in, fan_out):
+            ms = [torch.nn.Linear(fan_in, fan_out) for _ in range(buckets)]
+            self.weight = torch.stack([m.weight.detach() for m in ms])
+            self.bias = torch.stack([m.bias.detach() for m in ms])
+
+    if buckets > 1:
+        lin = [_Stack(l1, l2), _Stack(l2, l3), _Stack(l3, num_classes)]
+    else:
+        lin = [torch.nn.Linear(l1, l2), torch.nn.Linear(l2, l3), torch.nn.Linear(l3, num_classes)]
     p = {
         "nnue2score": torch.tensor(600.0),
         "visual_threshold": torch.full((fps,), 0.1),

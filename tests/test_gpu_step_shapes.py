@@ -30,38 +30,64 @@ SHAPES = {
     "c2": dict(grid=10, fps=8, image=32, l1=1024, l2=128, l3=32, classes=10, batch=512),
     "c3": dict(grid=10, fps=8, image=32, l1=1024, l2=128, l3=32, classes=100, batch=1024),
     "c4": dict(grid=32, fps=64, image=224, l1=1024, l2=128, l3=32, classes=1000, batch=128),
+    # BASELINE configs[2] as worded: 8 layer-stack buckets + clipped ReLU (build extension: the oracle is the definition,
+    # parity unpinned); "spread" draws samples of very different density so that every stack is exercised
+    "c3k8": dict(grid=10, fps=8, image=32, l1=1024, l2=128, l3=32, classes=100, batch=1024, buckets=8, clip=1.0),
+    "c3k8_spread": dict(grid=10, fps=8, image=32, l1=1024, l2=128, l3=32, classes=100, batch=1024, buckets=8, clip=1.0, spread=True),
 }
 
 
 def clean_batch(cfg, params, stride, gen, margin=1e-5, gate_margin=2e-5):
     """randn images / randint labels that keep the margins described above."""
     b, hw = cfg["batch"], cfg["image"]
-    images = torch.randn(b, 3, hw, hw, generator=gen)
+    clip = cfg.get("clip")
+
+    def draw(count):
+        x = torch.randn(count, 3, hw, hw, generator=gen)
+        if cfg.get("spread"):  # per-sample offset and gain (+ all-positive conv weights): feature counts over the whole range
+            x = x * (0.5 + torch.rand(count, 1, 1, 1, generator=gen)) + (3.2 * torch.rand(count, 1, 1, 1, generator=gen) - 1.6)
+        return x
+
+    images = draw(b)
     p64 = {k: v.double() for k, v in params.items()}
+    cls = [p64[f"classifier.classifier.{i}.{n}"] for i in (0, 2, 4) for n in ("weight", "bias")]
     t64 = p64["visual_threshold"].view(1, -1, 1, 1)
     for _ in range(64):
         x = F.conv2d(images.double(), p64["conv.weight"], stride=stride, padding=1)
         dirty = ((x - t64).abs() < margin).flatten(1).any(dim=1)
-        idx, _ = orc.active_lists(x, p64["visual_threshold"])
+        idx, n = orc.active_lists(x, p64["visual_threshold"])
         l0 = orc.pairwise(orc.ft_forward(p64["input.weight"], p64["input.bias"], idx, (idx >= 0).double()))
-        z1 = F.linear(l0, p64["classifier.classifier.0.weight"], p64["classifier.classifier.0.bias"])
-        z2 = F.linear(F.relu(z1), p64["classifier.classifier.2.weight"], p64["classifier.classifier.2.bias"])
+        act = (lambda t: t.clamp(0, clip)) if clip is not None else F.relu
+        if cls[0].dim() == 3:  # each sample through its own stack
+            k = orc.bucket_index(n, cls[0].shape[0], x[0].numel())
+            z1 = torch.einsum("bi,boi->bo", l0, cls[0][k]) + cls[1][k]
+            z2 = torch.einsum("bi,boi->bo", act(z1), cls[2][k]) + cls[3][k]
+        else:
+            z1 = F.linear(l0, cls[0], cls[1])
+            z2 = F.linear(act(z1), cls[2], cls[3])
         for z in (z1, z2):
-            dirty |= (z.abs() < gate_margin * float(z.abs().max())).any(dim=1)
+            scale = gate_margin * float(z.abs().max())
+            dirty |= (z.abs() < scale).any(dim=1)
+            if clip is not None:
+                dirty |= ((z - clip).abs() < scale).any(dim=1)
         if not bool(dirty.any()):
             break
-        images[dirty] = torch.randn(int(dirty.sum()), 3, hw, hw, generator=gen)
+        images[dirty] = draw(int(dirty.sum()))
     else:
         raise AssertionError("could not draw a batch that keeps the margins")
     return images, torch.randint(0, cfg["classes"], (b,), generator=gen)
 
 
-@pytest.mark.parametrize("name", ("c2", "c3", "c4"))
+@pytest.mark.parametrize("name", ("c2", "c3", "c4", "c3k8", "c3k8_spread"))
 def test_three_steps_at_the_baseline_shape_follow_the_oracle(name):
     cfg = SHAPES[name]
     torch.manual_seed(0)
     model = nnue.NNUE(nnue.GridFeatureSet(cfg["grid"], cfg["fps"]), cfg["l1"], cfg["l2"], cfg["l3"],
-                      num_classes=cfg["classes"], input_size=cfg["image"])
+                      num_classes=cfg["classes"], input_size=cfg["image"], num_ls_buckets=cfg.get("buckets", 1),
+                      clip_activations=cfg.get("clip"))
+    if cfg.get("spread"):
+        with torch.no_grad():
+            model.conv.weight.abs_()  # an image offset then moves all conv outputs of a sample the same way
     params = {k: v.detach().clone() for k, v in model.state_dict().items()}
     stride = orc.conv_stride(cfg["image"], cfg["grid"])
     model = model.to(DEV)
@@ -75,7 +101,9 @@ def test_three_steps_at_the_baseline_shape_follow_the_oracle(name):
     for s in range(3):
         images, labels = clean_batch(cfg, params, stride, gen)
         before = {k: v.clone() for k, v in params.items()}
-        _, ref_loss, ref_grads, keep = orc.loss_and_grads_explicit(params, images, labels, stride)
+        _, ref_loss, ref_grads, keep = orc.loss_and_grads_explicit(params, images, labels, stride, cfg.get("clip"))
+        if cfg.get("spread") and s == 0:
+            assert len(set(keep["bucket"].tolist())) == cfg["buckets"], "the spread batch must reach every layer stack"
         ref_norm = orc.sgd_step(params, ref_grads, bufs, OPT["lr"], OPT["momentum"], OPT["weight_decay"], OPT["max_grad_norm"])
         slot = s % 2  # steps 1.. replay the captured full-step graph, on alternating input slots
         was = {k: v.detach().clone() for k, v in tr.p.items()}

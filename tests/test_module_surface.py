@@ -77,8 +77,10 @@ def test_same_seed_same_weights_as_reference(name):
 
 
 def test_rejected_configurations():
-    with pytest.raises(NotImplementedError):
-        nnue.NNUE(num_ls_buckets=8)
+    with pytest.raises(ValueError):
+        nnue.NNUE(num_ls_buckets=0)
+    with pytest.raises(ValueError):
+        nnue.NNUE(num_ls_buckets=65)
     with pytest.raises(ValueError):
         nnue.NNUE(l1_size=33)
     with pytest.raises(NotImplementedError):
@@ -112,3 +114,29 @@ def test_clip_weights_and_quantized_data_on_cpu():
     assert q["metadata"]["quantized_one"] == 127.0 and abs(q["metadata"]["visual_threshold"] - 0.1) < 1e-7
     assert q["feature_transformer"]["weight"].dtype == torch.int8 and q["feature_transformer"]["bias"].dtype == torch.int32
     assert len(q["classifier"]["layers"]) == 3
+
+
+def test_bucketed_layer_stacks_surface():
+    """num_ls_buckets = K > 1 (build extension): same key names, a leading K on the classifier tensors,
+    every slice drawn like nn.Linear in the oracle's order; K = 1 stays the reference's SimpleClassifier."""
+    import nnue_oracle as orc
+    torch.manual_seed(11)
+    m = nnue.NNUE(nnue.GridFeatureSet(4, 8), 32, 8, 4, num_classes=5, num_ls_buckets=3)
+    assert isinstance(m.classifier, nnue.BucketedClassifier) and m.num_ls_buckets == 3
+    ref = orc.init_params(4, 8, 32, 8, 4, 5, 11, buckets=3)
+    sd = m.state_dict()
+    assert list(sd) == list(orc.PARAM_KEYS)
+    for k, v in ref.items():
+        assert torch.equal(sd[k], v), k
+    assert sd["classifier.classifier.0.weight"].shape == (3, 8, 32) and sd["classifier.classifier.4.bias"].shape == (3, 5)
+    one = nnue.NNUE(nnue.GridFeatureSet(4, 8), 32, 8, 4, num_classes=5, num_ls_buckets=1)
+    assert isinstance(one.classifier, nnue.SimpleClassifier)
+    # the selector (also what the kernels compute): min(K-1, n*K // (flat_ids+1))
+    n = torch.tensor([0, 1, 120, 121, 242, 243, 363, 364, 968, 5000])
+    assert torch.equal(nnue.bucket_of(n, 8, 968), orc.bucket_index(n, 8, 968))
+    assert nnue.bucket_of(n, 8, 968).tolist() == [0, 0, 0, 0, 1, 2, 2, 3, 7, 7]
+    # clip: only the classifier's Linear weights and the table
+    with torch.no_grad():
+        m.classifier.classifier[0].weight.fill_(3.0)
+    m._clip_weights()
+    assert float(m.classifier.classifier[0].weight.max()) == 1.0

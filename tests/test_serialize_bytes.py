@@ -138,3 +138,61 @@ def test_reference_engine_rejects_corrupt_header(tmp_path):
     np.zeros(32 * 32 * 3, dtype=np.float32).tofile(img)
     r = subprocess.run([str(ENGINE), str(bad), str(img), "32", "32"], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0
+
+
+def bucketed_model(k=8):
+    torch.manual_seed(5)
+    return nnue.NNUE(nnue.GridFeatureSet(10, 8), 64, 32, 8, num_classes=10, num_ls_buckets=k)
+
+
+def test_bucketed_file_layout(tmp_path):
+    """K layer-stack records behind a header that says K (what engine/src/nnue_engine.cpp:619-635 loops over); everything
+    before the stacks, and stack k itself, are the bytes a K = 1 model with bucket k's weights gives."""
+    import nnue_engine_oracle as eo
+    import nnue_oracle as orc
+    m = bucketed_model()
+    data = blob(m, tmp_path)
+    assert len(data) == orc.nnue_file_size(800, 8, 64, 32, 8, 10, buckets=8)
+    assert int.from_bytes(data[24:28], "little") == 8
+    (tmp_path / "k8.nnue").write_bytes(data)
+    parsed = eo.load_nnue(tmp_path / "k8.nnue")
+    assert parsed["buckets"] == 8 and len(parsed["stacks"]) == 8
+    stack_bytes = (len(data) - orc.nnue_file_size(800, 8, 64, 32, 8, 10, buckets=0))
+    assert stack_bytes % 8 == 0
+    per = stack_bytes // 8
+    head = len(data) - stack_bytes
+    for k in (0, 3, 7):
+        one = nnue.NNUE(nnue.GridFeatureSet(10, 8), 64, 32, 8, num_classes=10)
+        sd = {key: (v[k] if key.startswith("classifier.") else v) for key, v in m.state_dict().items()}
+        one.load_state_dict(sd)
+        single = blob(one, tmp_path)
+        assert single[28:head] == data[28:head] and single[:24] == data[:24]
+        assert single[head:] == data[head + k * per: head + (k + 1) * per], k
+    # checkpoint -> model keeps K
+    torch.save(m.state_dict(), tmp_path / "k8.pt")
+    again = serialize.load_model_from_checkpoint(tmp_path / "k8.pt")
+    assert again.num_ls_buckets == 8 and blob(again, tmp_path) == data
+
+
+@pytest.mark.skipif(not ENGINE.exists(), reason="oracle/_ref/nnue_inference not built (make -C oracle)")
+def test_reference_engine_loads_the_bucketed_file(tmp_path):
+    """The reference engine reads all K stacks and evaluates bucket 0 (engine/nnue_inference.cpp:44): same output as for
+    the single-stack file holding bucket 0's weights."""
+    m = bucketed_model()
+    path = tmp_path / "k8.nnue"
+    serialize.serialize_model(m, path)
+    one = nnue.NNUE(nnue.GridFeatureSet(10, 8), 64, 32, 8, num_classes=10)
+    one.load_state_dict({key: (v[0] if key.startswith("classifier.") else v) for key, v in m.state_dict().items()})
+    serialize.serialize_model(one, tmp_path / "k1.nnue")
+    img = tmp_path / "img.bin"
+    np.random.RandomState(2).rand(32 * 32 * 3).astype(np.float32).tofile(img)
+    outs = []
+    for f in (path, tmp_path / "k1.nnue"):
+        r = subprocess.run([str(ENGINE), str(f), str(img), "32", "32"], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout.strip())
+    assert outs[0] == outs[1] and len(outs[0].split(",")) == 11
+    # a truncated last stack is rejected by the loader
+    (tmp_path / "short.nnue").write_bytes(path.read_bytes()[:-40])
+    r = subprocess.run([str(ENGINE), str(tmp_path / "short.nnue"), str(img), "32", "32"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0
