@@ -36,7 +36,10 @@ WORKLOADS = {
     # name: grid, fps, image, l1, l2, l3, classes, per-GPU batch            
     "c1": dict(grid=10, fps=8, image=32, l1=64, l2=32, l3=8, classes=10, batch=32),
     "c2": dict(grid=10, fps=8, image=32, l1=1024, l2=128, l3=32, classes=10, batch=512),
-    "c3": dict(grid=10, fps=8, image=32, l1=1024, l2=128, l3=32, classes=100, batch=1024),  # K=1: buckets do not exist in the reference
+    # BASELINE configs[2]: 8 layer-stack buckets + clipped ReLU -- a build extension (the reference trains one stack with
+    # plain ReLU: SURVEY section 0, D1/D2); "c3k1" is the same shape as the reference has it
+    "c3": dict(grid=10, fps=8, image=32, l1=1024, l2=128, l3=32, classes=100, batch=1024, buckets=8, clip=1.0),
+    "c3k1": dict(grid=10, fps=8, image=32, l1=1024, l2=128, l3=32, classes=100, batch=1024),
     "c4": dict(grid=32, fps=64, image=224, l1=1024, l2=128, l3=32, classes=1000, batch=128),
 }
 OPT = dict(lr=0.01, momentum=0.9, weight_decay=2e-4, max_grad_norm=1.0)  # config/train_nnue.py:29-36
@@ -53,6 +56,10 @@ def parse():
     ap.add_argument("--density", type=float, default=None,
                     help="override visual_threshold per channel so about this fraction of features is active (SURVEY 8d sweep); "
                          "default: the reference's 0.1 threshold (~0.43)")
+    ap.add_argument("--spread", action="store_true",
+                    help="bucketed workloads: give every sample its own offset and gain (and make the conv weights positive) so "
+                         "that the active-feature counts, and with them the layer-stack buckets, cover the whole range; default "
+                         "randn images put nearly every sample into one bucket")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather-compare", action="store_true",
@@ -122,7 +129,7 @@ def cpu_baseline(cfg, budget_s):
     cores = min(os.cpu_count() or 1, 16)  # the box's CPU share for one GPU
     torch.set_num_threads(cores)
     stride = orc.conv_stride(cfg["image"], cfg["grid"])
-    params = orc.init_params(cfg["grid"], cfg["fps"], cfg["l1"], cfg["l2"], cfg["l3"], cfg["classes"], 0)
+    params = orc.init_params(cfg["grid"], cfg["fps"], cfg["l1"], cfg["l2"], cfg["l3"], cfg["classes"], 0, buckets=cfg.get("buckets", 1))
     gen = torch.Generator().manual_seed(1234)
     batch = cfg["batch"]
     images = torch.randn(batch, 3, cfg["image"], cfg["image"], generator=gen)
@@ -130,7 +137,7 @@ def cpu_baseline(cfg, budget_s):
     bufs = {}
 
     def one():
-        _, _, grads, _ = orc.loss_and_grads_loop(params, images, labels, stride)
+        _, _, grads, _ = orc.loss_and_grads_loop(params, images, labels, stride, cfg.get("clip"))
         orc.sgd_step(params, grads, bufs, OPT["lr"], OPT["momentum"], OPT["weight_decay"], OPT["max_grad_norm"])
 
     t0 = time.perf_counter()
@@ -175,7 +182,11 @@ def main():
     cfg = WORKLOADS[args.workload]
     torch.manual_seed(0)
     model = nnue.NNUE(nnue.GridFeatureSet(cfg["grid"], cfg["fps"]), cfg["l1"], cfg["l2"], cfg["l3"],
-                      num_classes=cfg["classes"], input_size=cfg["image"]).to(dev)
+                      num_classes=cfg["classes"], input_size=cfg["image"], num_ls_buckets=cfg.get("buckets", 1),
+                      clip_activations=cfg.get("clip")).to(dev)
+    if args.spread:
+        with torch.no_grad():
+            model.conv.weight.abs_()
     B = cfg["batch"]
     SLOTS = 4
     trainer = NnueTrainer(model, B, (cfg["image"], cfg["image"]), group=None, use_graph=not args.no_graph,
@@ -185,7 +196,10 @@ def main():
     # draws its own.  Steps rotate over the slots, so consecutive steps see different data.
     gen = torch.Generator().manual_seed(1234 + rank)
     for images, labels in trainer.inputs:
-        images.copy_(torch.randn(B, 3, cfg["image"], cfg["image"], generator=gen))
+        x = torch.randn(B, 3, cfg["image"], cfg["image"], generator=gen)
+        if args.spread:
+            x = x * (0.5 + torch.rand(B, 1, 1, 1, generator=gen)) + (3.2 * torch.rand(B, 1, 1, 1, generator=gen) - 1.6)
+        images.copy_(x)
         labels.copy_(torch.randint(0, cfg["classes"], (B,), generator=gen))
 
     if args.density is not None:
@@ -222,6 +236,8 @@ def main():
         elapsed = float(t.item())
     loss_after = float(trainer.loss)
     n_mean, n_max = trainer.active_stats()
+    bucket_hist = (torch.bincount(trainer.bucket_plan.bucket.long(), minlength=trainer.K).tolist()
+                   if trainer.bucket_plan is not None else None)
 
     # ---- instrumented pass: per-entry-point durations from HIP events on the launch stream
     # FeatureTransformer kernel family: dense MFMA products, bit-mask/LDS-staged gather kernels or id-list kernels
@@ -229,7 +245,7 @@ def main():
     names = (["nnue_ftm_conv_binarize"] if trainer.use_mfma else
              ["nnue_conv3x3_forward", {"bits": "nnue_binarize_bits", "list": "nnue_binarize_features"}[trainer.ft_path]])
     fwd_entry = f"{ftp}_forward_l1" if getattr(trainer, "fuse_l1", False) else f"{ftp}_forward"  # fused: + layer-1 slabs in the epilogue
-    names += [fwd_entry, "nnue_classifier_train_step"]
+    names += [fwd_entry] + (["nnue_bucket_group", "nnue_classifier_train_step_bucketed"] if trainer.K > 1 else ["nnue_classifier_train_step"])
     # weight + value gradient (+ tail rows) go through one C call; it is one launch at launch-sized shapes and the two
     # separate launches at the 224x224 shapes (policy in nnue_ftm_backward)
     merged = trainer.use_mfma and trainer.merge_backward
@@ -324,7 +340,11 @@ def main():
         try:
             torch.manual_seed(0)
             model_g = nnue.NNUE(nnue.GridFeatureSet(cfg["grid"], cfg["fps"]), cfg["l1"], cfg["l2"], cfg["l3"],
-                                num_classes=cfg["classes"], input_size=cfg["image"]).to(dev)
+                                num_classes=cfg["classes"], input_size=cfg["image"], num_ls_buckets=cfg.get("buckets", 1),
+                                clip_activations=cfg.get("clip")).to(dev)
+            if args.spread:
+                with torch.no_grad():
+                    model_g.conv.weight.abs_()
             if args.density is not None:
                 with torch.no_grad():
                     model_g.visual_threshold.copy_(model.visual_threshold)
@@ -397,11 +417,15 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: NNUE {cfg['image']}x{cfg['image']} grid {cfg['grid']}x{cfg['grid']}x{cfg['fps']} "
                                    f"F={cfg['grid'] ** 2 * cfg['fps']} -> {cfg['l1']}/{cfg['l2']}/{cfg['l3']} -> {cfg['classes']}, "
-                                   f"batch {B}/GPU, SGD m0.9 wd2e-4 clip1.0" + (f", thresholds set for density {args.density} and held (lr 0)" if args.density is not None else ""),
+                                   + (f"{cfg['buckets']} layer-stack buckets (selector: active-feature count), clipped ReLU [0, {cfg['clip']}] "
+                                      f"(build extension, parity unpinned), " if cfg.get("buckets", 1) > 1 else "")
+                                   + ("per-sample offset/gain spread, " if args.spread else "")
+                                   + f"batch {B}/GPU, SGD m0.9 wd2e-4 clip1.0" + (f", thresholds set for density {args.density} and held (lr 0)" if args.density is not None else ""),
                        "global_batch": B * world, "parallelism": f"dp{world}", "launch": "eager" if args.no_graph else "hipGraph",
                        "mean_active_features": round(n_mean, 1), "max_active_features": n_max,
                        "active_density": round(n_mean / ((cfg["image"] - 1) // max(1, (cfg["image"] - 1) // (cfg["grid"] - 1)) + 1) ** 2 / cfg["fps"], 4),
-                       "eager_ms_per_step_instrumented": round(eager_ms, 4), "loss_after": round(loss_after, 4)},
+                       "eager_ms_per_step_instrumented": round(eager_ms, 4), "loss_after": round(loss_after, 4),
+                       **({"num_ls_buckets": trainer.K, "samples_per_bucket_last_batch": bucket_hist} if bucket_hist is not None else {})},
             "roofline": roofline,
             "kernels": kernels,
         }

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 19
+#define NNUE_HIP_ABI_VERSION 20
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -366,7 +366,12 @@ int nnue_classifier_backward_bucketed(const float* x, int pairwise,
                                       void* scratch, int64_t scratch_bytes, const nnue_buckets* buckets,
                                       nnue_stream_t stream);
 /* forward + mean cross-entropy + backward of the bucketed block in one call (train.py:250-254, :360-361 on top of
- * nnue.py:728-734 per stack). */
+ * nnue.py:728-734 per stack).  phases bit 16 with K > 1 (pairwise block, L1 % 4 == 0): d_w1 is left to
+ * nnue_ftm_backward_bucketed; the per-sample kernel then runs once per GROUPED row and leaves that product's operands in
+ * grouped row order inside scratch -- d_z1 [tiles*16][L2] at nnue_classifier_train_dz1_grouped_offset and the block's
+ * input x [tiles*16][L1] at nnue_classifier_train_x_grouped_offset (byte offsets; padding rows zero; -1 for K <= 1). */
+int64_t nnue_classifier_train_dz1_grouped_offset(int B, int L1, int L2, int L3, int C, int K);
+int64_t nnue_classifier_train_x_grouped_offset(int B, int L1, int L2, int L3, int C, int K);
 int nnue_classifier_train_step_bucketed(const float* x, int pairwise,
                                         const float* w1, const float* b1, const float* w2, const float* b2,
                                         const float* w3, const float* b3, float clip,
@@ -377,6 +382,16 @@ int nnue_classifier_train_step_bucketed(const float* x, int pairwise,
                                         float* d_w3, float* d_b3,
                                         void* scratch, int64_t scratch_bytes, int phases,
                                         const nnue_buckets* buckets, nnue_stream_t stream);
+
+/* nnue_ftm_backward for bucketed layer stacks (declared with the FeatureTransformer entry points above): d_w1 [K][L2][L1],
+ * ft_grouped / d_z1_grouped in grouped row order (grouped_rows = 16 * nnue_bucket_tile_count rows, padding rows zero),
+ * seg [K+1] the buckets' row ranges.  The rider's tile family repeats per bucket and contracts only that bucket's rows
+ * (autograd of nnue.py:728-730 per stack, through the pairwise block nnue.py:660-666).  K == 1: nnue_ftm_backward. */
+int nnue_ftm_backward_bucketed(const uint8_t* bits, const float* sink, const float* d_out, const float* weight,
+                               int B, int F, int P, int L1, float* d_weight, float* d_bias, float* d_conv_out,
+                               const float* ft_grouped, const float* d_z1_grouped, int L2, float* d_w1,
+                               float* sq_partial, int K, const int32_t* seg, int grouped_rows,
+                               nnue_stream_t stream);
 
 /* ---- loss + step tail ---------------------------------------------------------- */
 

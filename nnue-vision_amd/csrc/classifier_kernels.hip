@@ -666,7 +666,9 @@ __global__ __launch_bounds__(NT) void tail_train_kernel(const float* __restrict_
                                                         int L2, int L3, int C, float* __restrict__ h1,
                                                         float* __restrict__ h2, float* __restrict__ logits,
                                                         float* __restrict__ sample_loss, float* __restrict__ d_logits,
-                                                        float* __restrict__ d_z1, float* __restrict__ d_z2, Buckets bk) {
+                                                        float* __restrict__ d_z1, float* __restrict__ d_z2, Buckets bk,
+                                                        const float* __restrict__ x, int L1, float* __restrict__ x_g,
+                                                        float* __restrict__ d_z1_g) {
   extern __shared__ float lds[];  // h1 [L2] | h2 [L3] | logits / d_logits [C] | d_z2 [L3] | red [8]
   constexpr int S = NT / 32;      // class slices of the d_z2 sum
   __shared__ float part_s[S][32];
@@ -675,7 +677,22 @@ __global__ __launch_bounds__(NT) void tail_train_kernel(const float* __restrict_
   float* lgs = h2s + L3;
   float* dz2s = lgs + C;
   float* red = dz2s + L3;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
+  int b = blockIdx.x;
+  // Grouped mode (d_z1_g != NULL; bucketed stacks whose d_w1 product rides in nnue_ftm_backward_bucketed): one workgroup per
+  // GROUPED row g.  It also leaves the operands of that product in grouped row order -- x_g[g] = x[b] (the
+  // FeatureTransformer output) and d_z1_g[g] = d_z1[b] -- and a padding row leaves zeros in both.
+  const int g = blockIdx.x;
+  if (d_z1_g) {
+    b = bk.rows[g];  // workgroup-uniform
+    if (b < 0) {
+      for (int i = tid; i < L1; i += NT) x_g[(size_t)g * L1 + i] = 0.0f;
+      for (int i = tid; i < L2; i += NT) d_z1_g[(size_t)g * L2 + i] = 0.0f;
+      return;
+    }
+    for (int i = tid * 4; i < L1; i += NT * 4)  // L1 % 4 == 0 (the rider's shapes); nothing below waits for this copy
+      *reinterpret_cast<float4*>(x_g + (size_t)g * L1 + i) = *reinterpret_cast<const float4*>(x + (size_t)b * L1 + i);
+  }
   if (bk.bucket) {  // this sample's layer stack
     const int kb = bk.bucket[b];
     b1 += (size_t)kb * L2; w2 += (size_t)kb * L3 * L2; b2 += (size_t)kb * L3; w3 += (size_t)kb * C * L3; b3 += (size_t)kb * C;
@@ -844,7 +861,9 @@ __global__ __launch_bounds__(NT) void tail_train_kernel(const float* __restrict_
       for (int u = 0; u < 16; ++u) s = fmaf(dz2s[j + u], w[u], s);
     }
     for (; j < L3; ++j) s = fmaf(dz2s[j], w2[(size_t)j * L2 + k], s);
-    d_z1[(size_t)b * L2 + k] = s * gate_fn(h1s[k], clip);
+    const float v = s * gate_fn(h1s[k], clip);
+    d_z1[(size_t)b * L2 + k] = v;
+    if (d_z1_g) d_z1_g[(size_t)g * L2 + k] = v;
   }
   __syncthreads();
 }
@@ -1133,7 +1152,7 @@ __global__ __launch_bounds__(256) void l1_backward_x_small_wgrad(const float* __
 // ---------------------------------------------------------------- fused training step of the classifier block
 namespace {
 struct TrainLayout {
-  int64_t part, d_z1, d_z2, d_logits, slabs, total;  // float offsets
+  int64_t part, d_z1, d_z2, d_logits, slabs, d_z1_g, x_g, total;  // float offsets
 };
 TrainLayout train_layout(const ClsPlan& p, int B, int L1, int L2, int L3, int C, int K = 1) {
   TrainLayout t{};
@@ -1147,6 +1166,10 @@ TrainLayout train_layout(const ClsPlan& p, int B, int L1, int L2, int L3, int C,
   t.d_z2 = take((int64_t)B * L3);
   t.d_logits = take((int64_t)B * C);
   t.slabs = take(p.bww_ksplit > 1 ? (int64_t)p.bww_ksplit * K * L2 * L1 : 0);
+  // bucketed stacks: grouped-row copies of d_z1 and of the block's input for the d_w1 product in nnue_ftm_backward_bucketed
+  const int64_t grows = K > 1 ? (int64_t)bucket_tiles(B, K) * 16 : 0;
+  t.d_z1_g = take(grows * L2);
+  t.x_g = take(grows * L1);
   t.total = off + 4;
   return t;
 }
@@ -1164,8 +1187,10 @@ int train_step_impl(const float* x, int pairwise, const float* w1, const float* 
   const bool ext_dw1 = (phases & 16) != 0;
   const bool ext_slabs = (phases & 8) != 0;
   const int K = bk.K;
-  NNUE_REQUIRE(K == 1 || !(ext_dw1 || ext_slabs), NNUE_E_ARG,
-               "nnue_classifier_train_step: phases bits 8 / 16 (products formed inside the FeatureTransformer launches) exist for one layer stack only");
+  NNUE_REQUIRE(K == 1 || !ext_slabs, NNUE_E_ARG,
+               "nnue_classifier_train_step: phases bit 8 (layer-1 slabs formed in the FeatureTransformer forward's epilogue) exists for one layer stack only");
+  NNUE_REQUIRE(K == 1 || !ext_dw1 || (pairwise && L1 % 4 == 0), NNUE_E_SHAPE,
+               "nnue_classifier_train_step: phases bit 16 with K > 1 needs the pairwise block and L1 %% 4 == 0");
   NNUE_REQUIRE(!ext_slabs || (pairwise && L1 % 64 == 0), NNUE_E_SHAPE,
                "nnue_classifier_train_step: phases bit 8 needs the pairwise block and L1 %% 64 == 0 (got L1=%d)", L1);
   NNUE_REQUIRE(d_w1 && d_b1 && d_w2 && d_b2 && d_w3 && d_b3, NNUE_E_ARG, "nnue_classifier_train_step: null gradient pointer");
@@ -1184,6 +1209,11 @@ int train_step_impl(const float* x, int pairwise, const float* w1, const float* 
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* base = static_cast<float*>(scratch);
   float *part = base + t.part, *d_z1 = base + t.d_z1, *d_z2 = base + t.d_z2, *d_logits = base + t.d_logits, *slabs = base + t.slabs;
+  // K > 1 with d_w1 left to nnue_ftm_backward_bucketed: the tail kernel runs per grouped row and leaves that product's operands
+  const bool grouped = K > 1 && ext_dw1;
+  float* d_z1_g = grouped ? base + t.d_z1_g : nullptr;
+  float* x_g = grouped ? base + t.x_g : nullptr;
+  const int tail_grid = grouped ? bk.tiles * 16 : B;
   const bool slab_pass = p.bww_mfma && p.bww_ksplit > 1;
   const int m_tiles = bk.rows ? bk.tiles : (B + 15) / 16;
   // bit 4: the d_w1 product runs in phase 1's d_x launch (both MFMA forms, d_x requested); a later phase-2 call with the
@@ -1211,8 +1241,8 @@ int train_step_impl(const float* x, int pairwise, const float* w1, const float* 
     }
     const bool vec = L2 % 4 == 0 && L3 % 4 == 0 && nnue_aligned16(w2) && nnue_aligned16(w3);
 #define NNUE_TAIL(NT, V)                                                                                                                  \
-  hipLaunchKernelGGL((tail_train_kernel<NT, V>), dim3(B), dim3(NT), (size_t)tail_lds, s, part, tail_slabs, b1, w2, b2, w3, b3, clip, labels, \
-                     grad_scale / (float)B, B, L2, L3, C, h1, h2, logits, sample_loss, d_logits, d_z1, d_z2, bk)
+  hipLaunchKernelGGL((tail_train_kernel<NT, V>), dim3(tail_grid), dim3(NT), (size_t)tail_lds, s, part, tail_slabs, b1, w2, b2, w3, b3, clip, \
+                     labels, grad_scale / (float)B, B, L2, L3, C, h1, h2, logits, sample_loss, d_logits, d_z1, d_z2, bk, x, L1, x_g, d_z1_g)
     if (C > 256) { if (vec) NNUE_TAIL(512, true); else NNUE_TAIL(512, false); }
     else { if (vec) NNUE_TAIL(128, true); else NNUE_TAIL(128, false); }
 #undef NNUE_TAIL
@@ -1267,6 +1297,16 @@ extern "C" int64_t nnue_classifier_train_scratch_bucketed(int B, int L1, int L2,
 extern "C" int64_t nnue_classifier_train_dz1_offset(int B, int L1, int L2, int L3, int C, int pairwise) {
   if (B <= 0 || L1 <= 0 || L2 <= 0 || L3 <= 0 || C <= 0) return -1;
   return train_layout(make_plan(B, L1, L2, pairwise), B, L1, L2, L3, C).d_z1 * (int64_t)sizeof(float);
+}
+
+extern "C" int64_t nnue_classifier_train_dz1_grouped_offset(int B, int L1, int L2, int L3, int C, int K) {
+  if (B <= 0 || L1 <= 0 || L2 <= 0 || L3 <= 0 || C <= 0 || K <= 1 || K > kMaxBuckets) return -1;
+  return train_layout(make_plan(B, L1, L2, 1, K), B, L1, L2, L3, C, K).d_z1_g * (int64_t)sizeof(float);
+}
+
+extern "C" int64_t nnue_classifier_train_x_grouped_offset(int B, int L1, int L2, int L3, int C, int K) {
+  if (B <= 0 || L1 <= 0 || L2 <= 0 || L3 <= 0 || C <= 0 || K <= 1 || K > kMaxBuckets) return -1;
+  return train_layout(make_plan(B, L1, L2, 1, K), B, L1, L2, L3, C, K).x_g * (int64_t)sizeof(float);
 }
 
 extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const float* w1, const float* b1, const float* w2,

@@ -276,9 +276,10 @@ __device__ __forceinline__ void fused_l1_epilogue(const FwdL1Epi& e, const Fused
 
 // One BM x BN output tile (linear tile index `tile`, K slab `ks`) by the 256 threads of a workgroup; `smem` is the
 // workgroup's LDS (gemm_lds_floats() floats, 16-byte aligned).
+// The tile contracts k in [k_lo, k_hi); `ks` only names the split-K slab the epilogue stores to.
 template <int BM, int BN, int BK, bool AKC, bool BKC, class Epi>
-__device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& ma, const Mat& mb, const Epi& epi, int M, int N, int K,
-                                          int klen, int tiles_n, int tile, int ks) {
+__device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& ma, const Mat& mb, const Epi& epi, int M, int N, int k_lo,
+                                          int k_hi, int tiles_n, int tile, int ks) {
   constexpr int LDA = AKC ? BK : BM + 4, LDB = BKC ? BK : BN + 4;
   float* __restrict__ As = smem;
   float* __restrict__ Bs = smem + (AKC ? BM : BK) * LDA;
@@ -293,8 +294,6 @@ __device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& m
   const int r = lane & 15, q = lane >> 4;
   const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
   const int m_base = tile_m * BM, n_base = tile_n * BN;
-  const int k_lo = ks * klen;
-  const int k_hi = (k_lo + klen < K) ? k_lo + klen : K;
   constexpr int AG = BM * BK / 1024, BG = BN * BK / 1024;  // float4 groups per thread
   constexpr int TM = BM / 32, TN = BN / 32;
   // staging coordinates of float4 group i: (row, k) with the memory-contiguous axis walked by consecutive lanes
@@ -447,14 +446,15 @@ __device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& m
 template <int BM, int BN, int BK, bool AKC, bool BKC, class Epi>
 __global__ __launch_bounds__(256) void ftm_gemm_kernel(Mat ma, Mat mb, Epi epi, int M, int N, int K, int klen, int tiles_n) {
   __shared__ __attribute__((aligned(16))) float smem[gemm_lds_floats<BM, BN, BK, AKC, BKC>()];
-  gemm_tile<BM, BN, BK, AKC, BKC, Epi>(smem, ma, mb, epi, M, N, K, klen, tiles_n, blockIdx.x, blockIdx.y);
+  const int k_lo = blockIdx.y * klen;
+  gemm_tile<BM, BN, BK, AKC, BKC, Epi>(smem, ma, mb, epi, M, N, k_lo, (k_lo + klen < K) ? k_lo + klen : K, tiles_n, blockIdx.x, blockIdx.y);
 }
 
 template <int BM, int BK>
 __global__ __launch_bounds__(256) void ftm_forward_l1_kernel(Mat ma, Mat mb, FwdL1Epi epi, int M, int N, int K, int tiles_n) {
   constexpr int kGemm = gemm_lds_floats<BM, 64, BK, true, false>(), kEpi = 2 * BM * kL1Ld;
   __shared__ __attribute__((aligned(16))) float smem[kGemm > kEpi ? kGemm : kEpi];
-  gemm_tile<BM, 64, BK, true, false, FwdL1Epi>(smem, ma, mb, epi, M, N, K, K + BK, tiles_n, blockIdx.x, 0);
+  gemm_tile<BM, 64, BK, true, false, FwdL1Epi>(smem, ma, mb, epi, M, N, 0, K, tiles_n, blockIdx.x, 0);
 }
 
 // out = bias + sink[b] * weight[F-1] + sum of the split-K slabs (fixed order)
@@ -549,6 +549,11 @@ struct CwArgs {  // classifier first-layer weight gradient riding in the same la
   Mat a, b;
   CwEpi e;
   int M, N, K, tiles_n, n_c;
+  // bucketed layer stacks (seg != NULL): d_z1 and ft are in GROUPED row order (nnue_bucket_group), bucket k owns rows
+  // seg[k] .. seg[k+1]; the tile family repeats per bucket (per_bucket tiles each), tile (k, t) contracts only that row
+  // range into d_w1[k] -- an empty bucket's tiles store zeros
+  const int* seg;
+  int per_bucket;
 };
 
 template <int WM, int WN, int WK, int VM, int VN, int VK>
@@ -561,11 +566,23 @@ __global__ __launch_bounds__(256) void ftm_backward_kernel(Mat wa, Mat wb, BwwEp
   __shared__ __attribute__((aligned(16))) float smem[kWV > kC ? kWV : kC];
   const int blk = blockIdx.x;
   if (blk < n_v) {  // the longer tiles (K = L1) are dispatched first
-    gemm_tile<VM, VN, VK, true, true, ValEpi>(smem, va, vb, ve, vM, vN, vK, vK + VK, v_tiles_n, blk, 0);
+    gemm_tile<VM, VN, VK, true, true, ValEpi>(smem, va, vb, ve, vM, vN, 0, vK, v_tiles_n, blk, 0);
   } else if (blk < n_v + n_w) {
-    gemm_tile<WM, WN, WK, false, false, BwwEpi>(smem, wa, wb, we, wM, wN, wK, wK + WK, w_tiles_n, blk - n_v, 0);
+    gemm_tile<WM, WN, WK, false, false, BwwEpi>(smem, wa, wb, we, wM, wN, 0, wK, w_tiles_n, blk - n_v, 0);
   } else if (blk < n_v + n_w + c.n_c) {
-    gemm_tile<WM, WN, WK, false, false, CwEpi>(smem, c.a, c.b, c.e, c.M, c.N, c.K, c.K + WK, c.tiles_n, blk - n_v - n_w, 0);
+    const int t = blk - n_v - n_w;
+    if (c.seg) {
+      const int kb = t / c.per_bucket;
+      const int k_lo = c.seg[kb], k_hi = c.seg[kb + 1];
+      Mat a = c.a, b = c.b;  // rows from k_hi on belong to the next bucket: end both windows there (reads as zero)
+      a.bytes = (unsigned)k_hi * (unsigned)a.ld * 4u;
+      b.bytes = (unsigned)k_hi * (unsigned)b.ld * 4u;
+      CwEpi e = c.e;
+      e.d_w1 += (size_t)kb * c.M * c.N;
+      gemm_tile<WM, WN, WK, false, false, CwEpi>(smem, a, b, e, c.M, c.N, k_lo, k_hi, c.tiles_n, t - kb * c.per_bucket, 0);
+    } else {
+      gemm_tile<WM, WN, WK, false, false, CwEpi>(smem, c.a, c.b, c.e, c.M, c.N, 0, c.K, c.tiles_n, t, 0);
+    }
   } else {
     const int i = blk - n_w - n_v - c.n_c;
     tail_rows_block(t, i % t.col_blocks, i / t.col_blocks);
@@ -842,9 +859,31 @@ extern "C" int nnue_ftm_backward_cw_supported(int B, int F, int P, int L1, int L
          L2 % 4 == 0 && ((long long)B + 256) * L2 * 4 < (1ll << 31);
 }
 
+namespace {
+int ftm_backward_impl(const uint8_t* bits, const float* sink, const float* d_out, const float* weight, int B, int F, int P, int L1,
+                      float* d_weight, float* d_bias, float* d_conv_out, const float* ft, const float* d_z1, int L2, float* d_w1,
+                      float* sq_partial, int K, const int32_t* seg, int grouped_rows, nnue_stream_t stream);
+}
 extern "C" int nnue_ftm_backward(const uint8_t* bits, const float* sink, const float* d_out, const float* weight, int B, int F, int P,
                                  int L1, float* d_weight, float* d_bias, float* d_conv_out, const float* ft, const float* d_z1, int L2,
                                  float* d_w1, float* sq_partial, nnue_stream_t stream) {
+  return ftm_backward_impl(bits, sink, d_out, weight, B, F, P, L1, d_weight, d_bias, d_conv_out, ft, d_z1, L2, d_w1, sq_partial, 1, nullptr, 0,
+                           stream);
+}
+extern "C" int nnue_ftm_backward_bucketed(const uint8_t* bits, const float* sink, const float* d_out, const float* weight, int B, int F,
+                                          int P, int L1, float* d_weight, float* d_bias, float* d_conv_out, const float* ft_grouped,
+                                          const float* d_z1_grouped, int L2, float* d_w1, float* sq_partial, int K, const int32_t* seg,
+                                          int grouped_rows, nnue_stream_t stream) {
+  NNUE_REQUIRE(K >= 1 && K <= 64, NNUE_E_ARG, "nnue_ftm_backward_bucketed: K=%d out of range", K);
+  NNUE_REQUIRE(K == 1 || !d_w1 || (seg && grouped_rows >= B && grouped_rows % 16 == 0), NNUE_E_ARG,
+               "nnue_ftm_backward_bucketed: d_w1 for K > 1 needs seg and the grouped row count (a multiple of 16, >= B)");
+  return ftm_backward_impl(bits, sink, d_out, weight, B, F, P, L1, d_weight, d_bias, d_conv_out, ft_grouped, d_z1_grouped, L2, d_w1, sq_partial,
+                           K, K > 1 ? seg : nullptr, K > 1 ? grouped_rows : 0, stream);
+}
+namespace {
+int ftm_backward_impl(const uint8_t* bits, const float* sink, const float* d_out, const float* weight, int B, int F, int P, int L1,
+                      float* d_weight, float* d_bias, float* d_conv_out, const float* ft, const float* d_z1, int L2, float* d_w1,
+                      float* sq_partial, int K, const int32_t* seg, int grouped_rows, nnue_stream_t stream) {
   NNUE_REQUIRE(bits && sink && d_out && weight && d_weight && d_bias && d_conv_out, NNUE_E_ARG, "nnue_ftm_backward: null pointer");
   const bool want_cw = d_w1 != nullptr;
   NNUE_REQUIRE(!want_cw || (ft && d_z1 && nnue_ftm_backward_cw_supported(B, F, P, L1, L2) && nnue_aligned16(ft) && nnue_aligned16(d_z1)),
@@ -879,12 +918,15 @@ extern "C" int nnue_ftm_backward(const uint8_t* bits, const float* sink, const f
   const Shape& svr = big_pair ? sv2 : sv;
   const int n_w = swr.tiles_m * swr.tiles_n, n_v = svr.tiles_m * svr.tiles_n, n_t = t.col_blocks * (1 + t.zero_slices);
   CwArgs cw{};
-  if (want_cw) {  // d_w1 [L2][L1] = d_z1^T [L2 x B] l0 [B x L1]
-    cw.a = Mat{d_z1, (unsigned)((size_t)B * L2 * 4), L2, kIntMax, kIntMax};
-    cw.b = Mat{ft, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, kIntMax};
+  if (want_cw) {  // d_w1 [L2][L1] = d_z1^T [L2 x B] l0 [B x L1]   (per bucket over its own grouped rows when seg != NULL)
+    const int rows = seg ? grouped_rows : B;
+    cw.a = Mat{d_z1, (unsigned)((size_t)rows * L2 * 4), L2, kIntMax, kIntMax};
+    cw.b = Mat{ft, (unsigned)((size_t)rows * L1 * 4), L1, kIntMax, kIntMax};
     cw.e = CwEpi{d_w1, L1, L1 / 2};
     cw.M = L2; cw.N = L1; cw.K = B; cw.tiles_n = (L1 + 63) / 64;
-    cw.n_c = ((L2 + swr.bm - 1) / swr.bm) * cw.tiles_n;  // tiles of the weight-gradient shape (both operands row-contiguous)
+    cw.per_bucket = ((L2 + swr.bm - 1) / swr.bm) * cw.tiles_n;  // tiles of the weight-gradient shape (both operands row-contiguous)
+    cw.seg = seg;
+    cw.n_c = cw.per_bucket * (seg ? K : 1);
   }
   const dim3 grid((unsigned)(n_w + n_v + cw.n_c + n_t));
 #define NNUE_FTM_BWD(WM, WN, WK, VM, VN, VK)                                                                                          \
@@ -896,6 +938,7 @@ extern "C" int nnue_ftm_backward(const uint8_t* bits, const float* sink, const f
 #undef NNUE_FTM_BWD
   return nnue_launch_status("nnue_ftm_backward");
 }
+}  // namespace
 
 // The forward with the classifier's layer-1 slabs formed in its epilogue (FwdL1Epi).  Taken for the shapes whose
 // forward is one launch without split-K (tile 32x64x128 or 64x64x64), an even pairwise split that falls on 32-column

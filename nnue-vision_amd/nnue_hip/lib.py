@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -71,6 +71,10 @@ SIGNATURES = {
     "nnue_ftm_backward_sq_count": (_c_i64, [_c_int, _c_int, _c_int, _c_int]),
     "nnue_ftm_backward": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p,
                                    _c_p, _c_p, _c_int, _c_p, _c_p, _c_p]),
+    "nnue_ftm_backward_bucketed": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p,
+                                            _c_p, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_int, _c_p]),
+    "nnue_classifier_train_dz1_grouped_offset": (_c_i64, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
+    "nnue_classifier_train_x_grouped_offset": (_c_i64, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
     "nnue_classifier_scratch": (_c_i64, [_c_int, _c_int, _c_int, _c_int]),
     "nnue_classifier_forward": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_f,
                                          _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p,
@@ -694,9 +698,11 @@ def ftm_backward_cw_supported(b: int, f: int, p: int, l1: int, l2: int) -> bool:
 def ftm_backward(d_out: torch.Tensor, weight: torch.Tensor, fm: FeatureMatrix, d_weight: Optional[torch.Tensor] = None,
                  d_bias: Optional[torch.Tensor] = None, dst: Optional[torch.Tensor] = None, ft: Optional[torch.Tensor] = None,
                  d_z1: Optional[torch.Tensor] = None, d_w1: Optional[torch.Tensor] = None,
-                 sq_partial: Optional[torch.Tensor] = None):
+                 sq_partial: Optional[torch.Tensor] = None, buckets=None):
     """(d_weight, d_bias, d_conv_out) in one launch; bitwise the results of ftm_backward_weight + ftm_backward_values.
-    With ft [B, L1], d_z1 [B, L2] and d_w1 [L2, L1] the launch also writes d_w1 = d_z1^T l0 (the pairwise block of ft)."""
+    With ft [B, L1], d_z1 [B, L2] and d_w1 [L2, L1] the launch also writes d_w1 = d_z1^T l0 (the pairwise block of ft).
+    buckets (a BucketPlan): d_w1 [K, L2, L1]; ft / d_z1 are then the GROUPED-row copies [tiles*16, .] the bucketed
+    classifier step left in its scratch."""
     d_out = _need(d_out, torch.float32, "d_out")
     weight = _need(weight, torch.float32, "input.weight")
     b, l1 = d_out.shape
@@ -711,16 +717,21 @@ def ftm_backward(d_out: torch.Tensor, weight: torch.Tensor, fm: FeatureMatrix, d
     elif dst.numel() != b * fm.positions:
         raise ValueError("ftm_backward: dst has the wrong size")
     l2 = 0
+    rows = b if buckets is None else buckets.tiles * 16
     if d_w1 is not None:
         ft = _need(ft, torch.float32, "ft")
         d_z1 = _need(d_z1, torch.float32, "d_z1")
-        l2 = d_w1.shape[0]
-        if ft.shape != (b, l1) or d_z1.numel() != b * l2 or d_w1.shape != (l2, l1) or not d_w1.is_contiguous():
+        l2 = d_w1.shape[-2]
+        want = (l2, l1) if buckets is None else (buckets.K, l2, l1)
+        if ft.shape != (rows, l1) or d_z1.numel() != rows * l2 or tuple(d_w1.shape) != want or not d_w1.is_contiguous():
             raise ValueError("ftm_backward: ft / d_z1 / d_w1 shape mismatch")
-    _call("nnue_ftm_backward", fm.bits.data_ptr(), fm.sink.data_ptr(), d_out.data_ptr(), weight.data_ptr(), b, fm.num_rows,
-          fm.positions, l1, d_weight.data_ptr(), d_bias.data_ptr(), dst.data_ptr(),
-          _ptr(ft if d_w1 is not None else None), _ptr(d_z1 if d_w1 is not None else None), l2, _ptr(d_w1), _ptr(sq_partial),
-          _stream(d_out))
+    args = (fm.bits.data_ptr(), fm.sink.data_ptr(), d_out.data_ptr(), weight.data_ptr(), b, fm.num_rows,
+            fm.positions, l1, d_weight.data_ptr(), d_bias.data_ptr(), dst.data_ptr(),
+            _ptr(ft if d_w1 is not None else None), _ptr(d_z1 if d_w1 is not None else None), l2, _ptr(d_w1), _ptr(sq_partial))
+    if buckets is None:
+        _call("nnue_ftm_backward", *args, _stream(d_out))
+    else:
+        _call("nnue_ftm_backward_bucketed", *args, buckets.K, buckets.seg.data_ptr(), rows, _stream(d_out))
     return d_weight, d_bias, dst
 
 
@@ -842,6 +853,13 @@ def classifier_train_scratch_bytes(b: int, l1: int, l2: int, l3: int, c: int, bu
 def classifier_train_dz1_offset(b: int, l1: int, l2: int, l3: int, c: int, pairwise: bool) -> int:
     """Byte offset of d_z1 [B, L2] inside the classifier's training scratch (valid after phase 1)."""
     return int(load().nnue_classifier_train_dz1_offset(b, l1, l2, l3, c, int(bool(pairwise))))
+
+
+def classifier_train_grouped_offsets(b: int, l1: int, l2: int, l3: int, c: int, buckets: int):
+    """Byte offsets of (d_z1 grouped [tiles*16, L2], x grouped [tiles*16, L1]) inside the bucketed training scratch."""
+    lib = load()
+    return (int(lib.nnue_classifier_train_dz1_grouped_offset(b, l1, l2, l3, c, buckets)),
+            int(lib.nnue_classifier_train_x_grouped_offset(b, l1, l2, l3, c, buckets)))
 
 
 def classifier_train_step(x, pairwise: bool, w1, b1, w2, b2, w3, b3, labels, grad_scale: float = 1.0, clip: float = 0.0,

@@ -218,7 +218,7 @@ class NnueTrainer:
         self.merge_backward = not self.branch and os.environ.get("NNUE_FTM_SPLIT_BACKWARD", "0") != "1"
         # the classifier's first-layer weight gradient rides in the merged FeatureTransformer backward launch (a third
         # tile family reading d_z1 out of the classifier's scratch) where that launch is used
-        self.ride_dw1 = (self.K == 1 and self.use_mfma and self.merge_backward and os.environ.get("NNUE_FTM_RIDE_DW1", "1") != "0"
+        self.ride_dw1 = (self.use_mfma and self.merge_backward and os.environ.get("NNUE_FTM_RIDE_DW1", "1") != "0"
                          and lib.ftm_backward_cw_supported(B, self.F, self.P, self.L1, self.L2))
         n_sq = lib.ftm_backward_sq_count(B, self.F, self.P, self.L1) if (self.use_mfma and self.merge_backward) else 0
         if (n_sq > 0 and not self.dp.collectives and optimizer == "sgd" and os.environ.get("NNUE_NORM_PARTIALS", "1") != "0"):
@@ -227,10 +227,18 @@ class NnueTrainer:
             if off % 4 == 0 and (rows * self.L1) % 4 == 0:
                 self.sq_partial = torch.empty((n_sq,), **f32)
                 self.sq_range = (off, off + rows * self.L1)
-        self.d_z1 = None
-        if self.ride_dw1:
+        self.d_z1 = self.ft_rider = None
+        if self.ride_dw1 and self.K == 1:
             off = lib.classifier_train_dz1_offset(B, self.L1, self.L2, self.L3, self.C, True)
             self.d_z1 = self.cls_scratch[off:off + B * self.L2 * 4].view(torch.float32).view(B, self.L2)
+            self.ft_rider = self.ft
+        elif self.ride_dw1:
+            # bucketed stacks: the rider contracts each bucket's own rows, so its operands are the grouped-row copies
+            # the classifier's per-sample kernel leaves in the scratch
+            rows = self.bucket_plan.tiles * 16
+            o_dz, o_x = lib.classifier_train_grouped_offsets(B, self.L1, self.L2, self.L3, self.C, self.K)
+            self.d_z1 = self.cls_scratch[o_dz:o_dz + rows * self.L2 * 4].view(torch.float32).view(rows, self.L2)
+            self.ft_rider = self.cls_scratch[o_x:o_x + rows * self.L1 * 4].view(torch.float32).view(rows, self.L1)
 
     # ------------------------------------------------------------------ hyper-parameters
     # The recorded update plan (and every graph captured from it) carries lr, momentum, weight decay and the clip norm
@@ -314,8 +322,9 @@ class NnueTrainer:
             if self.use_mfma and self.merge_backward:
                 # weight gradient, value gradient and tail rows share one launch (independent work, all read d_ft)
                 lib.ftm_backward(self.d_ft, p["input.weight"], self.fm, d_weight=g["input.weight"], d_bias=g["input.bias"],
-                                 dst=self.d_conv_out, ft=self.ft, d_z1=self.d_z1,
-                                 d_w1=g["classifier.classifier.0.weight"] if self.ride_dw1 else None, sq_partial=self.sq_partial)
+                                 dst=self.d_conv_out, ft=self.ft_rider, d_z1=self.d_z1,
+                                 d_w1=g["classifier.classifier.0.weight"] if self.ride_dw1 else None, sq_partial=self.sq_partial,
+                                 buckets=self.bucket_plan)
             elif self.use_mfma:
                 lib.ftm_backward_weight(self.d_ft, self.fm, d_weight=g["input.weight"], d_bias=g["input.bias"])
             elif self.use_bits:

@@ -203,3 +203,38 @@ def test_bucketed_model_forward_backward_against_the_oracle(cfg, clip):
     assert torch.equal(bucket, keep["bucket"])
     l0 = orc.pairwise(keep["ft"]).float().to(DEV)
     assert_close_logits(model.classifier(l0, bucket.to(DEV)), ref_logits, "stand-alone bucketed classifier")
+
+
+@pytest.mark.parametrize("ride", ("1", "0"))
+@pytest.mark.parametrize("use_graph", (False, True))
+def test_bucketed_trainer_step_against_the_oracle(monkeypatch, ride, use_graph):
+    """The fused trainer with K = 4 stacks: d_w1 from the per-bucket rider of the FeatureTransformer backward launch
+    (grouped-row operands) and from the classifier's own product -- both against the oracle, two SGD steps."""
+    from nnue_hip.trainer import NnueTrainer
+    monkeypatch.setenv("NNUE_FTM_RIDE_DW1", ride)
+    torch.manual_seed(3)
+    model = nnue.NNUE(nnue.GridFeatureSet(10, 8), 256, 32, 16, num_classes=10, num_ls_buckets=4, clip_activations=1.0)
+    with torch.no_grad():
+        model.conv.weight.abs_()
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    opt = dict(lr=0.05, momentum=0.9, weight_decay=1e-4, max_grad_norm=1.0)
+    tr = NnueTrainer(model, 80, (32, 32), use_graph=use_graph, **opt)
+    assert tr.K == 4 and tr.ride_dw1 == (ride == "1") and not tr.fuse_l1
+    gen = torch.Generator().manual_seed(12)
+    bufs = {}
+    for s in range(2):
+        images = spread_images(80, 32, gen)
+        labels = torch.randint(0, 10, (80,), generator=gen)
+        p64 = {k: v.double() for k, v in params.items()}
+        _, ref_loss, ref_grads, keep = orc.loss_and_grads_explicit(p64, images.double(), labels, 3, 1.0)
+        assert len(set(keep["bucket"].tolist())) == 4
+        loss = tr.step(images.to(DEV), labels.to(DEV))
+        assert abs(float(loss) - float(ref_loss)) <= 1e-4 * max(1.0, abs(float(ref_loss)))
+        got = tr.layout.views(tr.flat_grads)
+        for k, ref in ref_grads.items():
+            assert_close_grad(got[k], ref, f"step {s} {k}")
+        g32 = {k: v.float() for k, v in ref_grads.items()}
+        orc.sgd_step(params, g32, bufs, opt["lr"], opt["momentum"], opt["weight_decay"], opt["max_grad_norm"])
+        for k in orc.TRAINABLE_KEYS:
+            assert_close_grad(tr.p[k], params[k], f"step {s} parameter {k}", rtol=2e-5)
