@@ -249,7 +249,8 @@ def main():
     # weight + value gradient (+ tail rows) go through one C call; it is one launch at launch-sized shapes and the two
     # separate launches at the 224x224 shapes (policy in nnue_ftm_backward)
     merged = trainer.use_mfma and trainer.merge_backward
-    names += [f"{ftp}_backward"] if merged else [f"{ftp}_backward_weight", f"{ftp}_backward_values"]
+    bwd_entry = f"{ftp}_backward_bucketed" if (merged and trainer.K > 1) else f"{ftp}_backward"
+    names += [bwd_entry] if merged else [f"{ftp}_backward_weight", f"{ftp}_backward_values"]
     names += ["nnue_ste_conv_backward", "nnue_sgd_step"]
     timers = {k: [] for k in names}
     isteps = max(5, min(50, args.steps))
@@ -276,6 +277,8 @@ def main():
         alg = {f"{ftp}_forward": alg[f"{ftp}_forward"], f"{ftp}_backward": alg[f"{ftp}_backward_values"] + alg[f"{ftp}_backward_weight"]}
     if fwd_entry != f"{ftp}_forward":
         alg[fwd_entry] = alg.pop(f"{ftp}_forward")
+    if merged and bwd_entry != f"{ftp}_backward":
+        alg[bwd_entry] = alg.pop(f"{ftp}_backward")
     kernels = {k: {"avg_us": round(dur_us[k], 2), **({"alg_GBps": round(alg[k] / dur_us[k] * 1e-3, 1)} if k in alg and dur_us[k] > 0 else {})}
                for k in names}
     def pmc_traffic(entry):
@@ -289,7 +292,7 @@ def main():
         kernels = data.get("workloads", {}).get(args.workload) or (data.get("kernels") if args.workload == "c2" else None)
         if not kernels:
             return None
-        want = {"nnue_ftm_forward": ("ftm_gemm_kernel", "FwdEpi"), "nnue_ftm_forward_l1": ("ftm_forward_l1_kernel", ""), "nnue_ftm_backward": ("ftm_backward_kernel", ""), "nnue_ftm_backward_weight": ("ftm_gemm_kernel", "BwwEpi"),
+        want = {"nnue_ftm_forward": ("ftm_gemm_kernel", "FwdEpi"), "nnue_ftm_forward_l1": ("ftm_forward_l1_kernel", ""), "nnue_ftm_backward": ("ftm_backward_kernel", ""), "nnue_ftm_backward_bucketed": ("ftm_backward_kernel", ""), "nnue_ftm_backward_weight": ("ftm_gemm_kernel", "BwwEpi"),
                 "nnue_ftm_backward_values": ("ftm_gemm_kernel", "ValEpi"),
                 "nnue_ftb_forward": ("ftb_gather_kernel", ", 0,"), "nnue_ftb_backward_weight": ("ftb_gather_kernel", ", 1,"),
                 "nnue_ftb_backward_values": ("ftb_values_kernel", ""), "nnue_ft_forward": ("ft_forward_wide", ""),
@@ -316,6 +319,7 @@ def main():
         flops[f"{ftp}_backward"] = flops[f"{ftp}_backward_weight"] + flops[f"{ftp}_backward_values"]
         if getattr(trainer, "ride_dw1", False):  # + the classifier's first-layer weight gradient riding in the launch
             flops[f"{ftp}_backward"] += 2.0 * B * cfg["l1"] * cfg["l2"]
+        flops[f"{ftp}_backward_bucketed"] = flops[f"{ftp}_backward"]
         flops[f"{ftp}_forward_l1"] = flops[f"{ftp}_forward"] + 2.0 * B * cfg["l1"] * cfg["l2"]  # + the layer-1 product
         achieved = flops[dom] / (dur_us[dom] * 1e-6) / 1e12 if dur_us[dom] > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -921,24 +921,27 @@ int64_t plan_scratch_floats(const ClsPlan& p, int B, int L1, int L2, int L3, int
 // ---- bucket selector + grouping (one workgroup; B a few thousand at most matters for speed, any B is correct) -----
 // bucket[b] = min(K-1, n[b] * K / (P + 1))  (P = flat ids of the map; P == 0: n[b] already IS the bucket, clamped)
 // then a stable counting sort of the samples into bucket-homogeneous 16-row tiles.
-__global__ __launch_bounds__(256) void bucket_group_kernel(const int* __restrict__ n, int B, int P, int K, int* __restrict__ bucket,
-                                                           int* __restrict__ rows, int* __restrict__ tile_bucket,
-                                                           int* __restrict__ seg, int tiles) {
-  __shared__ int cnt[kMaxBuckets], start[kMaxBuckets + 1], run[kMaxBuckets], wtot[4][kMaxBuckets];
+constexpr int kGroupThreads = 1024;  // one pass over a batch of 1024: every phase of the kernel is a latency, not work
+__global__ __launch_bounds__(kGroupThreads) void bucket_group_kernel(const int* __restrict__ n, int B, int P, int K,
+                                                                     int* __restrict__ bucket, int* __restrict__ rows,
+                                                                     int* __restrict__ tile_bucket, int* __restrict__ seg, int tiles) {
+  constexpr int NW = kGroupThreads / 64;
+  __shared__ int cnt[kMaxBuckets], start[kMaxBuckets + 1], run[kMaxBuckets], wtot[NW][kMaxBuckets];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   auto select = [&](int nb) {
     int k = P > 0 ? (int)(((long long)nb * K) / ((long long)P + 1)) : nb;
     k = k < 0 ? 0 : k;
     return k < K - 1 ? k : K - 1;
   };
+  const int first = tid < B ? select(n[tid]) : -1;  // this thread's sample of the first chunk (requested before anything else)
   if (tid < K) { cnt[tid] = 0; run[tid] = 0; }
+  for (int i = tid; i < tiles * 16; i += kGroupThreads) rows[i] = -1;
   __syncthreads();
-  for (int b = tid; b < B; b += 256) {
-    const int k = select(n[b]);
+  for (int b = tid; b < B; b += kGroupThreads) {
+    const int k = b == tid ? first : select(n[b]);
     bucket[b] = k;
     atomicAdd(&cnt[k], 1);  // integer: exact in any order
   }
-  for (int i = tid; i < tiles * 16; i += 256) rows[i] = -1;
   __syncthreads();
   if (tid == 0) {
     start[0] = 0;
@@ -946,15 +949,15 @@ __global__ __launch_bounds__(256) void bucket_group_kernel(const int* __restrict
   }
   __syncthreads();
   if (tid <= K) seg[tid] = start[tid];
-  for (int t = tid; t < tiles; t += 256) {
+  for (int t = tid; t < tiles; t += kGroupThreads) {
     int kb = -1;
     for (int k = 0; k < K; ++k)
       if (16 * t >= start[k] && 16 * t < start[k] + cnt[k]) kb = k;
     tile_bucket[t] = kb;
   }
-  for (int chunk = 0; chunk < B; chunk += 256) {  // stable: ascending sample index inside a bucket
+  for (int chunk = 0; chunk < B; chunk += kGroupThreads) {  // stable: ascending sample index inside a bucket
     const int b = chunk + tid;
-    const int k = b < B ? select(n[b]) : -1;
+    const int k = chunk == 0 ? first : (b < B ? select(n[b]) : -1);
     int rank = 0;
     for (int kk = 0; kk < K; ++kk) {
       const unsigned long long m = __ballot(k == kk);
@@ -967,8 +970,13 @@ __global__ __launch_bounds__(256) void bucket_group_kernel(const int* __restrict
       for (int w = 0; w < wave; ++w) pre += wtot[w][k];
       rows[start[k] + run[k] + pre + rank] = b;
     }
+    if (chunk + kGroupThreads >= B) break;  // uniform
     __syncthreads();
-    if (tid < K) run[tid] += (wtot[0][tid] + wtot[1][tid]) + (wtot[2][tid] + wtot[3][tid]);
+    if (tid < K) {
+      int add = 0;
+      for (int w = 0; w < NW; ++w) add += wtot[w][tid];
+      run[tid] += add;
+    }
     __syncthreads();
   }
 }
@@ -1096,7 +1104,7 @@ extern "C" int nnue_bucket_group(const int32_t* n, int B, int P, int K, int32_t*
   NNUE_REQUIRE(n && bucket && rows && tile_bucket && seg, NNUE_E_ARG, "nnue_bucket_group: null pointer");
   NNUE_REQUIRE(B > 0 && P >= 0 && K >= 1, NNUE_E_ARG, "nnue_bucket_group: B=%d P=%d K=%d out of range", B, P, K);
   NNUE_REQUIRE(K <= kMaxBuckets, NNUE_E_SHAPE, "nnue_bucket_group: %d layer stacks (at most %d)", K, kMaxBuckets);
-  hipLaunchKernelGGL(bucket_group_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), n, B, P, K, bucket, rows, tile_bucket,
+  hipLaunchKernelGGL(bucket_group_kernel, dim3(1), dim3(kGroupThreads), 0, static_cast<hipStream_t>(stream), n, B, P, K, bucket, rows, tile_bucket,
                      seg, bucket_tiles(B, K));
   return nnue_launch_status("nnue_bucket_group");
 }
