@@ -274,6 +274,56 @@ __device__ __forceinline__ void fused_l1_epilogue(const FwdL1Epi& e, const Fused
   }
 }
 
+// Epilogue shared by the f32 and the bf16-split tiles (the C/D lane map of the MFMA is the same for both): accumulator
+// register e of lane 16 q + r holds C[row 4 q + e][col r]; every epilogue operand is loaded before the first store so
+// that the loads overlap.  `smem` is free when this runs (the K loop ended with a barrier).
+template <int BM, int BN, class Epi>
+__device__ __forceinline__ void store_tile(float* __restrict__ smem, const Epi& epi, const f32x4 (&acc)[BM / 32][BN / 32], int M, int N,
+                                           int m_base, int n_base, int m0, int n0, int tile, int ks) {
+  constexpr int TM = BM / 32, TN = BN / 32;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  float2 cv[TN];
+  float pre[TM][TN][4];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int n = n_base + n0 + 16 * t + r;
+    cv[t] = n < N ? epi.col(n) : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m_base + m0 + 16 * i + 4 * q + e;
+        pre[i][t][e] = (m < M && n < N) ? epi.pre(m, n) : 0.0f;
+      }
+  }
+  float sqacc = 0.0f;
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int n = n_base + n0 + 16 * t + r;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m_base + m0 + 16 * i + 4 * q + e;
+        if (m < M && n < N) {
+          epi.store(m, n, acc[i][t][e], cv[t], pre[i][t][e], ks);
+          if constexpr (Epi::kSq) sqacc = fmaf(acc[i][t][e], acc[i][t][e], sqacc);
+        }
+      }
+  }
+  if constexpr (Epi::kSq) {
+    if (epi.sq) {  // uniform; fixed order: lanes by butterfly, waves 0..3
+#pragma unroll
+      for (int sh = 32; sh >= 1; sh >>= 1) sqacc += __shfl_xor(sqacc, sh);
+      if (lane == 0) smem[wave] = sqacc;
+      __syncthreads();
+      if (tid == 0) epi.sq[tile] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+    }
+  }
+}
+
 // One BM x BN output tile (linear tile index `tile`, K slab `ks`) by the 256 threads of a workgroup; `smem` is the
 // workgroup's LDS (gemm_lds_floats() floats, 16-byte aligned).
 // The tile contracts k in [k_lo, k_hi); `ks` only names the split-K slab the epilogue stores to.
@@ -400,47 +450,203 @@ __device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& m
     fused_l1_epilogue<BM>(epi, l1pre, smem, acc, m_base, tile_n, m0, n0, r, q, wave, tid);
     return;
   } else {
-  // accumulator register e of lane 16 q + r holds C[row 4 q + e][col r]; every epilogue operand is loaded before
-  // the first store so that the loads overlap
-  float2 cv[TN];
-  float pre[TM][TN][4];
-#pragma unroll
-  for (int t = 0; t < TN; ++t) {
-    const int n = n_base + n0 + 16 * t + r;
-    cv[t] = n < N ? epi.col(n) : make_float2(0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int m = m_base + m0 + 16 * i + 4 * q + e;
-        pre[i][t][e] = (m < M && n < N) ? epi.pre(m, n) : 0.0f;
-      }
+    store_tile<BM, BN, Epi>(smem, epi, acc, M, N, m_base, n_base, m0, n0, tile, ks);
   }
-  float sqacc = 0.0f;
+}
+
+// ---- the two products whose A operand is the binary map, on the bf16 matrix unit -----------------------------------
+// out = A W and d_W = A^T d_out multiply a {0,1} matrix -- exact in bf16 -- by an f32 one.  A float splits EXACTLY into
+// three bf16 terms by truncation (hi = top 8 significant bits, mid = top 8 bits of the remainder, lo = what is left: at
+// most 8 bits, so nothing is dropped): x = hi + mid + lo identically.  Every product 1 * term is exact, so three
+// v_mfma_f32_16x16x32_bf16 (f32 accumulate) over the three planes compute the same sum of the same numbers as the f32
+// MFMA -- in another order, like every other path here -- at 3 x 16 cycles per 32 k against 8 x 32 cycles for
+// v_mfma_f32_16x16x4_f32 (MI355X_MICROARCH.md: the f32-input MFMA runs at 1/16 of the bf16 rate).
+//
+// Tile BM x BN x 128, waves 2 x 2.  Both operands sit in LDS as [row][k] bf16 images (256-byte rows, 16-byte chunk index
+// XOR-swizzled by the row -- the layout the f32 kernel's KC images use, conflict-free for ds_read_b128): A one image, the
+// f32 operand three (planes).  The f32 operand is contiguous along its rows in memory (table rows in the forward, d_out
+// rows in the weight gradient), i.e. along n, while the MFMA wants 8 consecutive k per lane: a thread therefore owns an
+// 8 k x 4 n block (eight 16-byte loads), splits it in registers and writes, per n, one 16-byte chunk of 8 k per plane.
+// The split is 4 VALU per value + 1.5 for packing; it is amortised over the BM rows of the tile, so tall tiles matter
+// more here than for the f32 kernel.
+using bf16x8 = __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16;
+constexpr int kBfK = 128;  // K tile
+template <int BM, int BN>
+constexpr int gemm_bf_lds_bytes() { return (BM + 3 * BN) * kBfK * 2; }
+
+__device__ __forceinline__ int bf_img(int row, int chunk) { return row * (kBfK * 2) + ((chunk ^ (row & 15)) << 4); }  // byte offset
+
+// four {0,1} bytes -> four bf16 (two words)
+__device__ __forceinline__ void bytes_to_bf16(unsigned x, unsigned& w0, unsigned& w1) {
+  w0 = ((x & 0xffu) | ((x & 0xff00u) << 8)) * 0x3f80u;
+  w1 = (((x >> 16) & 0xffu) | ((x >> 8) & 0xff0000u)) * 0x3f80u;
+}
+
+template <int BM, int BN, bool AKC, class Epi>
+__device__ __forceinline__ void gemm_tile_bf(unsigned char* __restrict__ smem, const Mat& ma, const Mat& mb, const Epi& epi, int M, int N,
+                                             int k_lo, int k_hi, int tiles_n, int tile, int ks) {
+  static_assert(BN == 64, "the f32 operand's staging assigns one 8 k x 4 n block per thread: 128 x 64 per K tile");
+  static_assert(BM == 32 || BM == 64 || BM == 128, "tile heights");
+  constexpr int TM = BM / 32, TN = BN / 32;
+  unsigned char* __restrict__ As = smem;
+  unsigned char* __restrict__ Bs = smem + BM * kBfK * 2;  // plane p at + p * BN * 256
+  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ma.p), 0, ma.bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(mb.p), 0, mb.bytes, 0x00020000);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
+  const int m_base = tile_m * BM, n_base = tile_n * BN;
+  const int m0 = (wave >> 1) * (BM / 2), n0 = (wave & 1) * (BN / 2);
+  auto b_col = [&](int n_abs) {
+    if constexpr (Epi::kFusedL1) return epi.col(n_abs);
+    else return n_abs;
+  };
+  // ---- staging coordinates
+  // f32 operand: thread = (k block of 8, n block of 4); lanes walk n first (coalesced 16-byte loads along a row)
+  const int bn4 = (tid & 15) * 4, bk8 = (tid >> 4) * 8;
+  const int b_off = b_col(n_base + bn4) * 4;  // byte offset inside a row
+  // A, forward (bytes contiguous along k): 16-byte groups, (row, 16 k); BM * 8 groups
+  // A, weight gradient (bytes contiguous along m): thread = (k block of 8, m block of 4); BM / 4 x 16 blocks
+  constexpr int AGK = BM * 8 / 256;                 // forward: 16-byte loads per thread
+  constexpr int AGR = (BM / 4) * 16 / 256 ? (BM / 4) * 16 / 256 : 1;  // weight gradient: 8 x 4 blocks per thread (BM = 32: half the threads)
+  u32x4 ra[AKC ? AGK : 1];
+  unsigned rat[AKC ? 1 : AGR][8];
+  u32x4 rb[8];
+  auto fetch = [&](int k0) {
+    if constexpr (AKC) {
 #pragma unroll
-  for (int t = 0; t < TN; ++t) {
-    const int n = n_base + n0 + 16 * t + r;
+      for (int i = 0; i < AGK; ++i) {
+        const int g = tid + 256 * i, row = g >> 3, k = k0 + (g & 7) * 16;
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsa, (m_base + row) * ma.ld + k, 0, 0);
+      }
+    } else {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < AGR; ++i) {
+        const int g = tid + 256 * i;
+        const int m4 = (g % (BM / 4)) * 4, k8 = (g / (BM / 4)) * 8;
+        const bool on = g < (BM / 4) * 16;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int m = m_base + m0 + 16 * i + 4 * q + e;
-        if (m < M && n < N) {
-          epi.store(m, n, acc[i][t][e], cv[t], pre[i][t][e], ks);
-          if constexpr (Epi::kSq) sqacc = fmaf(acc[i][t][e], acc[i][t][e], sqacc);
+        for (int j = 0; j < 8; ++j)
+          rat[i][j] = __builtin_amdgcn_raw_buffer_load_b32(rsa, on ? (k0 + k8 + j) * ma.ld + m_base + m4 : 0x7ffffff0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsb, (k0 + bk8 + j) * mb.ld * 4 + b_off, 0, 0);
+  };
+  auto stage = [&]() {
+    if constexpr (AKC) {
+#pragma unroll
+      for (int i = 0; i < AGK; ++i) {
+        const int g = tid + 256 * i, row = g >> 3, c = (g & 7) * 2;
+        u32x4 lo, hi;
+        unsigned a, b;
+        bytes_to_bf16(ra[i][0], a, b); lo[0] = a; lo[1] = b;
+        bytes_to_bf16(ra[i][1], a, b); lo[2] = a; lo[3] = b;
+        bytes_to_bf16(ra[i][2], a, b); hi[0] = a; hi[1] = b;
+        bytes_to_bf16(ra[i][3], a, b); hi[2] = a; hi[3] = b;
+        *reinterpret_cast<u32x4*>(As + bf_img(row, c)) = lo;
+        *reinterpret_cast<u32x4*>(As + bf_img(row, c + 1)) = hi;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < AGR; ++i) {
+        const int g = tid + 256 * i;
+        if (g < (BM / 4) * 16) {
+          const int m4 = (g % (BM / 4)) * 4, c = g / (BM / 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {  // byte e of the eight words = 8 consecutive k of row m4 + e
+            u32x4 v;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const unsigned sel = 0x0c000c00u | (unsigned)e | ((unsigned)(4 + e) << 16);  // [lo.byte e, 0, hi.byte e, 0]
+              v[t] = __builtin_amdgcn_perm(rat[i][2 * t + 1], rat[i][2 * t], sel) * 0x3f80u;
+            }
+            *reinterpret_cast<u32x4*>(As + bf_img(m4 + e, c)) = v;
+          }
         }
       }
-  }
-  if constexpr (Epi::kSq) {
-    if (epi.sq) {  // uniform; fixed order: lanes by butterfly, waves 0..3 (the K loop ended with a barrier: smem is free)
-#pragma unroll
-      for (int sh = 32; sh >= 1; sh >>= 1) sqacc += __shfl_xor(sqacc, sh);
-      if (lane == 0) smem[wave] = sqacc;
-      __syncthreads();
-      if (tid == 0) epi.sq[tile] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
     }
+    // exact three-way split of the 8 k x 4 n block, packed along k
+    u32x4 pl[3][4];  // [plane][n]: 8 bf16
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      unsigned h[2][4], m[2][4], l[2][4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = __uint_as_float(rb[2 * t + u][e]);
+          const unsigned hb = __float_as_uint(x) & 0xffff0000u;
+          const float r1 = x - __uint_as_float(hb);
+          const unsigned mb_ = __float_as_uint(r1) & 0xffff0000u;
+          const float r2 = r1 - __uint_as_float(mb_);
+          h[u][e] = hb; m[u][e] = mb_; l[u][e] = __float_as_uint(r2);
+        }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {  // word t of column e: k = 2 t (low half) and 2 t + 1 (high half)
+        pl[0][e][t] = __builtin_amdgcn_perm(h[1][e], h[0][e], 0x07060302u);
+        pl[1][e][t] = __builtin_amdgcn_perm(m[1][e], m[0][e], 0x07060302u);
+        pl[2][e][t] = __builtin_amdgcn_perm(l[1][e], l[0][e], 0x07060302u);
+      }
+    }
+#pragma unroll
+    for (int pnum = 0; pnum < 3; ++pnum)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) *reinterpret_cast<u32x4*>(Bs + pnum * (BN * kBfK * 2) + bf_img(bn4 + e, bk8 >> 3)) = pl[pnum][e];
+  };
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  FusedL1Pre<Epi::kFusedL1 ? BM : 32> l1pre;
+  if constexpr (Epi::kFusedL1) fused_l1_prefetch<BM>(epi, l1pre, m_base, tile_n, m0, n0, r, q, wave);
+  fetch(k_lo);
+  for (int k0 = k_lo; k0 < k_hi; k0 += kBfK) {
+    stage();
+    __syncthreads();
+    if (k0 + kBfK < k_hi) fetch(k0 + kBfK);
+#pragma unroll
+    for (int kb = 0; kb < kBfK / 32; ++kb) {
+      const int c = kb * 4 + q;  // this lane's 8 k of the 32-k block
+      bf16x8 a[TM], b[3][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(As + bf_img(m0 + 16 * i + r, c));
+#pragma unroll
+      for (int pnum = 0; pnum < 3; ++pnum)
+#pragma unroll
+        for (int t = 0; t < TN; ++t) b[pnum][t] = *reinterpret_cast<const bf16x8*>(Bs + pnum * (BN * kBfK * 2) + bf_img(n0 + 16 * t + r, c));
+      // smallest terms first; consecutive MFMAs go to different accumulators
+#pragma unroll
+      for (int pnum = 2; pnum >= 0; --pnum)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int t = 0; t < TN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[pnum][t], acc[i][t], 0, 0, 0);
+    }
+    __syncthreads();
   }
+  if constexpr (Epi::kFusedL1) {
+    fused_l1_epilogue<BM>(epi, l1pre, reinterpret_cast<float*>(smem), acc, m_base, tile_n, m0, n0, r, q, wave, tid);
+  } else {
+    store_tile<BM, BN, Epi>(reinterpret_cast<float*>(smem), epi, acc, M, N, m_base, n_base, m0, n0, tile, ks);
   }
+}
+
+template <int BM, int BN, bool AKC, class Epi>
+__global__ __launch_bounds__(256) void ftm_gemm_bf_kernel(Mat ma, Mat mb, Epi epi, int M, int N, int K, int klen, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[gemm_bf_lds_bytes<BM, BN>()];
+  const int k_lo = blockIdx.y * klen;
+  gemm_tile_bf<BM, BN, AKC, Epi>(smem, ma, mb, epi, M, N, k_lo, (k_lo + klen < K) ? k_lo + klen : K, tiles_n, blockIdx.x, blockIdx.y);
+}
+
+template <int BM>
+__global__ __launch_bounds__(256) void ftm_forward_l1_bf_kernel(Mat ma, Mat mb, FwdL1Epi epi, int M, int N, int K, int tiles_n) {
+  constexpr int kGemm = gemm_bf_lds_bytes<BM, 64>(), kEpi = 2 * BM * kL1Ld * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kGemm > kEpi ? kGemm : kEpi];
+  gemm_tile_bf<BM, 64, true, FwdL1Epi>(smem, ma, mb, epi, M, N, 0, K, tiles_n, blockIdx.x, 0);
 }
 
 template <int BM, int BN, int BK, bool AKC, bool BKC, class Epi>
@@ -589,6 +795,42 @@ __global__ __launch_bounds__(256) void ftm_backward_kernel(Mat wa, Mat wb, BwwEp
   }
 }
 
+// The same launch with the weight-gradient tiles on the bf16 matrix unit (gemm_tile_bf, WM x 64 x 128); value-gradient
+// tiles (both operands f32) and the rider keep the f32 MFMA.
+template <int WM, int VM, int VN, int VK>
+__global__ __launch_bounds__(256) void ftm_backward_bf_kernel(Mat wa, Mat wb, BwwEpi we, int wM, int wN, int wK, int w_tiles_n, int n_w,
+                                                              Mat va, Mat vb, ValEpi ve, int vM, int vN, int vK, int v_tiles_n, int n_v,
+                                                              CwArgs c, TailRows t) {
+  constexpr int kW = gemm_bf_lds_bytes<WM, 64>(), kV = gemm_lds_floats<VM, VN, VK, true, true>() * 4;
+  constexpr int kC = gemm_lds_floats<32, 64, 128, false, false>() * 4;
+  constexpr int kWV = kW > kV ? kW : kV;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_b[kWV > kC ? kWV : kC];
+  float* smem = reinterpret_cast<float*>(smem_b);
+  const int blk = blockIdx.x;
+  if (blk < n_v) {
+    gemm_tile<VM, VN, VK, true, true, ValEpi>(smem, va, vb, ve, vM, vN, 0, vK, v_tiles_n, blk, 0);
+  } else if (blk < n_v + n_w) {
+    gemm_tile_bf<WM, 64, false, BwwEpi>(smem_b, wa, wb, we, wM, wN, 0, wK, w_tiles_n, blk - n_v, 0);
+  } else if (blk < n_v + n_w + c.n_c) {
+    const int t2 = blk - n_v - n_w;
+    if (c.seg) {
+      const int kb = t2 / c.per_bucket;
+      const int k_lo = c.seg[kb], k_hi = c.seg[kb + 1];
+      Mat a = c.a, b = c.b;
+      a.bytes = (unsigned)k_hi * (unsigned)a.ld * 4u;
+      b.bytes = (unsigned)k_hi * (unsigned)b.ld * 4u;
+      CwEpi e = c.e;
+      e.d_w1 += (size_t)kb * c.M * c.N;
+      gemm_tile<32, 64, 128, false, false, CwEpi>(smem, a, b, e, c.M, c.N, k_lo, k_hi, c.tiles_n, t2 - kb * c.per_bucket, 0);
+    } else {
+      gemm_tile<32, 64, 128, false, false, CwEpi>(smem, c.a, c.b, c.e, c.M, c.N, 0, c.K, c.tiles_n, t2, 0);
+    }
+  } else {
+    const int i = blk - n_w - n_v - c.n_c;
+    tail_rows_block(t, i % t.col_blocks, i / t.col_blocks);
+  }
+}
+
 // bits[b][p] = conv_out[b][p] > thr[channel] as a byte, n[b] = active positions, sink[b] = active positions >= F-1.
 // grid (B, slices); integer-valued atomics into host-zeroed counters when a sample is split (exact in any order).
 __global__ __launch_bounds__(256) void ftm_binarize_kernel(const float* __restrict__ conv_out, const float* __restrict__ thr,
@@ -648,14 +890,20 @@ struct Shape {
   int cfg;  // 0: 32x64x128   1: 64x64x64   2: 128x64x32   3: 64x128x32
   int bm, bn, bk, tiles_m, tiles_n, ksplit, klen;
 };
-constexpr int kCfg[6][3] = {{32, 64, 128}, {64, 64, 64}, {128, 64, 32}, {64, 128, 32}, {128, 64, 64}, {64, 128, 64}};
+constexpr int kCfg[9][3] = {{32, 64, 128}, {64, 64, 64}, {128, 64, 32}, {64, 128, 32}, {128, 64, 64}, {64, 128, 64},
+                            {32, 64, 128}, {64, 64, 128}, {128, 64, 128}};  // 6..8: bf16-split tiles (gemm_tile_bf)
+
+// The two products over the binary map run on the bf16 matrix unit (exact three-way split of the f32 operand) unless
+// NNUE_FTM_BF16=0; NNUE_FTM_BF_BM forces the bf16 tile height (developer knob).
+bool use_bf16() { return env_int("NNUE_FTM_BF16", 1) != 0; }  // read per call: tests switch it inside one process
 
 // prefer_m: the operand re-read per M tile is the big one (the table, in forward and value gradient), so take tall
 // tiles; otherwise (weight gradient: the map is re-read per N tile) take wide ones.  The largest preferred shape
 // that still gives every CU a workgroup wins; the forward of a small batch (M <= 128: one tall tile covers it, the
 // table is then read exactly once) splits K until there are about two workgroups per CU.
-Shape plan(int M, int N, int K, bool prefer_m, bool allow_split) {
+Shape plan(int M, int N, int K, bool prefer_m, bool allow_split, bool bf_ok = false) {
   static const int force_cfg = env_int("NNUE_FTM_CFG", -1), force_split = env_int("NNUE_FTM_KSPLIT", 0);
+  const int force_bf_bm = env_int("NNUE_FTM_BF_BM", 0);
   const int order_m[3] = {2, 1, 0}, order_n[3] = {3, 1, 0};
   const int* order = prefer_m ? order_m : order_n;
   auto tiles = [&](int c) { return (long long)((M + kCfg[c][0] - 1) / kCfg[c][0]) * ((N + kCfg[c][1] - 1) / kCfg[c][1]); };
@@ -665,6 +913,16 @@ Shape plan(int M, int N, int K, bool prefer_m, bool allow_split) {
   const bool small_m = allow_split && M <= 128;
   if (small_m) cfg = 2;
   if (force_cfg >= 0 && force_cfg < 6) cfg = force_cfg;
+  if (bf_ok && use_bf16()) {
+    // The split of the f32 operand (5.5 VALU per value) is amortised over the tile's rows, so only tall tiles pay:
+    // 128 or 64 rows where they still fill the chip, the split-K forward of a small batch (128 rows).  Launch-sized
+    // products that would need 32-row tiles stay on the f32 MFMA (measured at the CIFAR batch-512 shape: forward 21.8 us
+    // with 32-row bf16 tiles, 25.7 with 64-row ones that leave half the CUs idle, 20.3 with the f32 kernel).
+    for (int c = 8; c >= 7; --c)
+      if (tiles(c) >= 256) { cfg = c; break; }
+    if (small_m) cfg = 8;
+    if (force_bf_bm == 32 || force_bf_bm == 64 || force_bf_bm == 128) cfg = force_bf_bm == 32 ? 6 : force_bf_bm == 64 ? 7 : 8;
+  }
   Shape s;
   s.cfg = cfg;
   s.bm = kCfg[cfg][0]; s.bn = kCfg[cfg][1]; s.bk = kCfg[cfg][2];
@@ -696,7 +954,17 @@ void launch(hipStream_t st, const Shape& s, Mat ma, Mat mb, Epi epi, int M, int 
     case 2: NNUE_FTM_LAUNCH(128, 64, 32); break;
     case 3: NNUE_FTM_LAUNCH(64, 128, 32); break;
     case 4: NNUE_FTM_LAUNCH(128, 64, 64); break;
-    default: NNUE_FTM_LAUNCH(64, 128, 64); break;
+    case 5: NNUE_FTM_LAUNCH(64, 128, 64); break;
+    default:
+      if constexpr (!BKC && Epi::kAU8) {  // bf16-split tiles: the map times an f32 operand that is contiguous along its rows
+#define NNUE_FTM_LAUNCH_BF(BM) \
+  hipLaunchKernelGGL((ftm_gemm_bf_kernel<BM, 64, AKC, Epi>), grid, dim3(256), 0, st, ma, mb, epi, M, N, K, s.klen, s.tiles_n)
+        if (s.cfg == 6) NNUE_FTM_LAUNCH_BF(32);
+        else if (s.cfg == 7) NNUE_FTM_LAUNCH_BF(64);
+        else NNUE_FTM_LAUNCH_BF(128);
+#undef NNUE_FTM_LAUNCH_BF
+      }
+      break;
   }
 #undef NNUE_FTM_LAUNCH
 }
@@ -728,7 +996,7 @@ extern "C" int nnue_ftm_supported(int F, int P, int L1) {
 extern "C" int64_t nnue_ftm_scratch(int B, int F, int P, int L1) {
   if (B <= 0 || F <= 0 || P <= 0 || L1 <= 0) return 0;
   const int direct = (F - 1 < P) ? F - 1 : P;
-  const Shape s = plan(B, L1, direct > 0 ? direct : 1, true, true);
+  const Shape s = plan(B, L1, direct > 0 ? direct : 1, true, true, true);
   return s.ksplit > 1 ? (int64_t)s.ksplit * B * L1 * (int64_t)sizeof(float) : 0;
 }
 
@@ -757,7 +1025,7 @@ extern "C" int nnue_ftm_forward(const uint8_t* bits, const float* sink, const fl
                "nnue_ftm_forward: pointers must be 16-byte aligned");
   const int direct = (F - 1 < P) ? F - 1 : P;
   const int K = direct > 0 ? direct : 1;  // F == 1: only the sink row; the product runs over one zero column
-  const Shape s = plan(B, L1, K, true, true);
+  const Shape s = plan(B, L1, K, true, true, true);
   const int64_t need = s.ksplit > 1 ? (int64_t)s.ksplit * B * L1 * (int64_t)sizeof(float) : 0;
   NNUE_REQUIRE(scratch_bytes >= need && (need == 0 || (scratch && nnue_aligned16(scratch))), NNUE_E_SCRATCH,
                "nnue_ftm_forward: scratch %lld < %lld bytes", (long long)scratch_bytes, (long long)need);
@@ -795,7 +1063,7 @@ int backward_weight_impl(const uint8_t* bits, const float* sink, const float* d_
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int direct = (F - 1 < P) ? F - 1 : P;
   if (d_weight && direct > 0) {
-    const Shape s = plan(direct, L1, B, false, false);
+    const Shape s = plan(direct, L1, B, false, false, true);
     launch<false, false>(st, s, Mat{bits, (unsigned)((size_t)B * P), P, kIntMax, kIntMax},
                          Mat{d_out, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, kIntMax}, BwwEpi{d_weight, L1, s.ksplit == 1 ? sq : nullptr},
                          direct, L1, B);
@@ -824,6 +1092,12 @@ extern "C" int nnue_ftm_backward_values(const uint8_t* bits, const float* d_out,
 // separate launches for tile-shape pairs that are not instantiated.
 namespace {
 // the shape pair the merged launch is used for (also the condition for the d_w1 tile family to ride along)
+// weight-gradient tile height of the merged launch when it runs on the bf16 matrix unit (0: f32 tiles)
+int merged_bf_wm() {
+  const int wm = env_int("NNUE_FTM_BF_WM", 64);
+  return use_bf16() ? (wm == 32 ? 32 : 64) : 0;
+}
+
 bool merged_backward_shape(int B, int F, int P, int L1, bool* big) {
   const int direct = (F - 1 < P) ? F - 1 : P;
   if (direct <= 0) return false;
@@ -845,11 +1119,12 @@ extern "C" int64_t nnue_ftm_backward_sq_count(int B, int F, int P, int L1) {
   if (direct <= 0) return 0;
   bool big = false;
   if (merged_backward_shape(B, F, P, L1, &big)) {
+    if (const int wm = merged_bf_wm()) return (int64_t)((direct + wm - 1) / wm) * ((L1 + 63) / 64);
     if (big) return (int64_t)((direct + 63) / 64) * ((L1 + 63) / 64);
     const Shape s = plan(direct, L1, B, false, false);
     return (int64_t)s.tiles_m * s.tiles_n;
   }
-  const Shape s = plan(direct, L1, B, false, false);
+  const Shape s = plan(direct, L1, B, false, false, true);
   return s.ksplit == 1 ? (int64_t)s.tiles_m * s.tiles_n : 0;
 }
 
@@ -914,7 +1189,10 @@ int ftm_backward_impl(const uint8_t* bits, const float* sink, const float* d_out
   const BwwEpi we{d_weight, L1, sq_partial};
   const ValEpi ve{bits, d_conv_out, P};
   const TailRows t = tail_rows(d_out, sink, B, L1, direct, F, d_weight, d_bias);
-  const Shape& swr = big_pair ? sw2 : sw;
+  const int bf_wm = merged_bf_wm();
+  Shape sw3 = sw;  // bf16 weight-gradient tiles: bf_wm x 64 x 128
+  if (bf_wm) { sw3.bm = bf_wm; sw3.bn = 64; sw3.bk = 128; sw3.tiles_m = (direct + bf_wm - 1) / bf_wm; sw3.tiles_n = (L1 + 63) / 64; }
+  const Shape& swr = bf_wm ? sw3 : big_pair ? sw2 : sw;
   const Shape& svr = big_pair ? sv2 : sv;
   const int n_w = swr.tiles_m * swr.tiles_n, n_v = svr.tiles_m * svr.tiles_n, n_t = t.col_blocks * (1 + t.zero_slices);
   CwArgs cw{};
@@ -924,7 +1202,8 @@ int ftm_backward_impl(const uint8_t* bits, const float* sink, const float* d_out
     cw.b = Mat{ft, (unsigned)((size_t)rows * L1 * 4), L1, kIntMax, kIntMax};
     cw.e = CwEpi{d_w1, L1, L1 / 2};
     cw.M = L2; cw.N = L1; cw.K = B; cw.tiles_n = (L1 + 63) / 64;
-    cw.per_bucket = ((L2 + swr.bm - 1) / swr.bm) * cw.tiles_n;  // tiles of the weight-gradient shape (both operands row-contiguous)
+    const int cw_bm = bf_wm ? 32 : swr.bm;  // the rider keeps f32 tiles: the weight-gradient shape, or 32 x 64 x 128 beside bf16 tiles
+    cw.per_bucket = ((L2 + cw_bm - 1) / cw_bm) * cw.tiles_n;
     cw.seg = seg;
     cw.n_c = cw.per_bucket * (seg ? K : 1);
   }
@@ -932,9 +1211,16 @@ int ftm_backward_impl(const uint8_t* bits, const float* sink, const float* d_out
 #define NNUE_FTM_BWD(WM, WN, WK, VM, VN, VK)                                                                                          \
   hipLaunchKernelGGL((ftm_backward_kernel<WM, WN, WK, VM, VN, VK>), grid, dim3(256), 0, st, wa, wb, we, direct, L1, B, swr.tiles_n, n_w, va, \
                      vb, ve, B, P, L1, svr.tiles_n, n_v, cw, t)
-  if (big_pair) NNUE_FTM_BWD(64, 64, 64, 64, 64, 64);
+#define NNUE_FTM_BWD_BF(WM, VM, VN, VK)                                                                                                  \
+  hipLaunchKernelGGL((ftm_backward_bf_kernel<WM, VM, VN, VK>), grid, dim3(256), 0, st, wa, wb, we, direct, L1, B, swr.tiles_n, n_w, va, vb, ve, \
+                     B, P, L1, svr.tiles_n, n_v, cw, t)
+  const bool v_small = !big_pair && sv.cfg == 0;
+  if (bf_wm == 64) { if (v_small) NNUE_FTM_BWD_BF(64, 32, 64, 128); else NNUE_FTM_BWD_BF(64, 64, 64, 64); }
+  else if (bf_wm == 32) { if (v_small) NNUE_FTM_BWD_BF(32, 32, 64, 128); else NNUE_FTM_BWD_BF(32, 64, 64, 64); }
+  else if (big_pair) NNUE_FTM_BWD(64, 64, 64, 64, 64, 64);
   else if (sv.cfg == 0) NNUE_FTM_BWD(32, 64, 128, 32, 64, 128);
   else NNUE_FTM_BWD(32, 64, 128, 64, 64, 64);
+#undef NNUE_FTM_BWD_BF
 #undef NNUE_FTM_BWD
   return nnue_launch_status("nnue_ftm_backward");
 }
@@ -947,8 +1233,8 @@ extern "C" int nnue_ftm_forward_l1_supported(int B, int F, int P, int L1, int L2
   if (!nnue_ftm_supported(F, P, L1) || !shape_ok(B, F, P, L1) || L1 % 64 != 0 || L2 <= 0) return 0;
   const int direct = (F - 1 < P) ? F - 1 : P;
   if (direct <= 0) return 0;
-  const Shape s = plan(B, L1, direct, true, true);
-  return (s.cfg == 0 || s.cfg == 1) && s.ksplit == 1;
+  const Shape s = plan(B, L1, direct, true, true, true);
+  return (s.cfg == 0 || s.cfg == 1 || s.cfg == 6 || s.cfg == 7) && s.ksplit == 1;
 }
 
 extern "C" int nnue_ftm_forward_l1(const uint8_t* bits, const float* sink, const float* weight, const float* bias, const float* w1, int B,
@@ -960,12 +1246,14 @@ extern "C" int nnue_ftm_forward_l1(const uint8_t* bits, const float* sink, const
                "nnue_ftm_forward_l1: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int direct = (F - 1 < P) ? F - 1 : P;
-  const Shape s = plan(B, L1, direct, true, true);
+  const Shape s = plan(B, L1, direct, true, true, true);
   const Mat ma{bits, (unsigned)((size_t)B * P), P, kIntMax, kIntMax}, mb{weight, (unsigned)((size_t)direct * L1 * 4), L1, kIntMax, kIntMax};
   const FwdL1Epi epi{bias, weight + (size_t)(F - 1) * L1, sink, out, w1, part, B, L1, L2, L1 / 2};
   const dim3 grid((unsigned)(s.tiles_m * s.tiles_n));
   if (s.cfg == 0) hipLaunchKernelGGL((ftm_forward_l1_kernel<32, 128>), grid, dim3(256), 0, st, ma, mb, epi, B, L1, direct, s.tiles_n);
-  else hipLaunchKernelGGL((ftm_forward_l1_kernel<64, 64>), grid, dim3(256), 0, st, ma, mb, epi, B, L1, direct, s.tiles_n);
+  else if (s.cfg == 1) hipLaunchKernelGGL((ftm_forward_l1_kernel<64, 64>), grid, dim3(256), 0, st, ma, mb, epi, B, L1, direct, s.tiles_n);
+  else if (s.cfg == 6) hipLaunchKernelGGL((ftm_forward_l1_bf_kernel<32>), grid, dim3(256), 0, st, ma, mb, epi, B, L1, direct, s.tiles_n);
+  else hipLaunchKernelGGL((ftm_forward_l1_bf_kernel<64>), grid, dim3(256), 0, st, ma, mb, epi, B, L1, direct, s.tiles_n);
   return nnue_launch_status("nnue_ftm_forward_l1");
 }
 
