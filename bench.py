@@ -251,6 +251,10 @@ def main():
     merged = trainer.use_mfma and trainer.merge_backward
     bwd_entry = f"{ftp}_backward_bucketed" if (merged and trainer.K > 1) else f"{ftp}_backward"
     names += [bwd_entry] if merged else [f"{ftp}_backward_weight", f"{ftp}_backward_values"]
+    if getattr(trainer, "fuse_table_update", False):  # weight gradient formed and consumed in the update (no d_weight)
+        names = [n for n in names if n not in (f"{ftp}_backward", f"{ftp}_backward_bucketed", f"{ftp}_backward_weight")]
+        names += [f"{ftp}_backward_values", f"{ftp}_gram_sqnorm", f"{ftp}_backward_tail_rows", f"{ftp}_backward_weight_update"]
+        names = list(dict.fromkeys(names))
     names += ["nnue_ste_conv_backward", "nnue_sgd_step"]
     timers = {k: [] for k in names}
     isteps = max(5, min(50, args.steps))
@@ -279,6 +283,10 @@ def main():
         alg[fwd_entry] = alg.pop(f"{ftp}_forward")
     if merged and bwd_entry != f"{ftp}_backward":
         alg[bwd_entry] = alg.pop(f"{ftp}_backward")
+    fused_update = getattr(trainer, "fuse_table_update", False)
+    if fused_update:  # value gradient as its own launch; the weight gradient is formed inside the update product
+        alg = {fwd_entry: (n_mean + 1) * row * B, f"{ftp}_backward_values": (n_mean + 1) * row * B,
+               f"{ftp}_backward_weight_update": n_mean * row * B}
     kernels = {k: {"avg_us": round(dur_us[k], 2), **({"alg_GBps": round(alg[k] / dur_us[k] * 1e-3, 1)} if k in alg and dur_us[k] > 0 else {})}
                for k in names}
     def pmc_traffic(entry):
@@ -320,6 +328,7 @@ def main():
         if getattr(trainer, "ride_dw1", False):  # + the classifier's first-layer weight gradient riding in the launch
             flops[f"{ftp}_backward"] += 2.0 * B * cfg["l1"] * cfg["l2"]
         flops[f"{ftp}_backward_bucketed"] = flops[f"{ftp}_backward"]
+        flops[f"{ftp}_backward_weight_update"] = flops[f"{ftp}_backward_weight"]
         flops[f"{ftp}_forward_l1"] = flops[f"{ftp}_forward"] + 2.0 * B * cfg["l1"] * cfg["l2"]  # + the layer-1 product
         achieved = flops[dom] / (dur_us[dom] * 1e-6) / 1e12 if dur_us[dom] > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 20
+#define NNUE_HIP_ABI_VERSION 21
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -383,6 +383,30 @@ int nnue_classifier_train_step_bucketed(const float* x, int pairwise,
                                         void* scratch, int64_t scratch_bytes, int phases,
                                         const nnue_buckets* buckets, nnue_stream_t stream);
 
+/* The table's weight gradient consumed where it is produced (single rank, SGD): clip_grad_norm_ needs the global norm
+ * before any parameter moves (train.py:363-366), and
+ *     || A^T D ||_F^2 = sum_{b,b'} (A A^T)_{bb'} (D D^T)_{bb'}      (A = the map [B][direct], D = d_out [B][L1])
+ * gives the table's share from two B x B Gram matrices without forming the [direct][L1] gradient.
+ * nnue_ftm_gram_sqnorm leaves nnue_ftm_gram_sq_count(B, L1) partial sums (unscaled; sum = that squared norm, formed as
+ * sum (G_A D) . D so that D D^T is not needed either) for nnue_sgd_step(ext_partial, ..., coef_out,
+ * ext_applied_elsewhere = 1); gram is [B*B] floats of scratch.  nnue_ftm_backward_tail_rows forms the rows the product does not cover (d_bias, row F-1, zero
+ * rows: what nnue_ftm_backward_weight adds to its product).  nnue_ftm_backward_weight_update then runs the product
+ * d_W = A^T d_out (autograd of nnue.py:702-708) and, element by element in its epilogue, the optimizer's update
+ *     g = coef[0]*grad_scale*d_W + wd*w ;  m = first_step ? g : momentum*m + g ;  w -= lr*m       (train.py:457-464)
+ * on table rows [0, direct) -- the same arithmetic nnue_sgd_step applies -- so d_weight is never written or read back
+ * (268 MB each way at the 224x224 configuration).  momentum_rows may be NULL when momentum == 0. */
+int64_t nnue_ftm_gram_sq_count(int B, int L1);
+int nnue_ftm_gram_sqnorm(const uint8_t* bits, const float* d_out, int B, int F, int P, int L1,
+                         float* gram, float* sq_partial, nnue_stream_t stream);
+/* (autograd of nnue.py:691, :701-708 for the bias row and the clamp-sink row F-1) */
+int nnue_ftm_backward_tail_rows(const float* sink, const float* d_out, int B, int F, int P, int L1,
+                                float* d_weight, float* d_bias, nnue_stream_t stream);
+/* (autograd of nnue.py:702-708 + train.py:363-366, :457-464, see above) */
+int nnue_ftm_backward_weight_update(const uint8_t* bits, const float* d_out, int B, int F, int P, int L1,
+                                    float* weight, float* momentum_rows, const float* coef,
+                                    float lr, float momentum, float weight_decay, float grad_scale,
+                                    int first_step, nnue_stream_t stream);
+
 /* nnue_ftm_backward for bucketed layer stacks (declared with the FeatureTransformer entry points above): d_w1 [K][L2][L1],
  * ft_grouped / d_z1_grouped in grouped row order (grouped_rows = 16 * nnue_bucket_tile_count rows, padding rows zero),
  * seg [K+1] the buckets' row ranges.  The rider's tile family repeats per bucket and contracts only that bucket's rows
@@ -454,7 +478,11 @@ int nnue_engine_evaluate_logits(const nnue_engine_model* m, const float* images,
  * elements (a multiple of 4 of them); ste_fps * 28 <= 4096.  All five are NULL / 0 otherwise.
  * ext_partial != NULL: ext_count sums of squares (unscaled) that a producer formed for grads[ext_lo, ext_hi) (multiples of
  * 4, e.g. nnue_ftm_backward's sq_partial for the FeatureTransformer weight rows): the norm launch skips that range and
- * the partials enter the norm in index order, multiplied by grad_scale^2.  ext_count <= 65536. */
+ * the partials enter the norm in index order, multiplied by grad_scale^2.  ext_count <= 65536.
+ * coef_out != NULL: the clip coefficient c is also left in that device float.  ext_applied_elsewhere != 0 (needs
+ * ext_partial and coef_out): grads[ext_lo, ext_hi) does not exist -- its producer applies the update itself afterwards
+ * (nnue_ftm_backward_weight_update, reading coef_out) -- so this call neither reads that range of grads nor touches that
+ * range of params / momentum_buf. */
 int64_t nnue_sgd_scratch(int64_t count);
 int nnue_sgd_step(float* params, float* grads, float* momentum_buf, int64_t count,
                   float lr, float momentum, float weight_decay, float max_norm, float grad_scale,
@@ -462,7 +490,7 @@ int nnue_sgd_step(float* params, float* grads, float* momentum_buf, int64_t coun
                   const float* ste_partial, int ste_chunks, int ste_fps,
                   float* ste_d_thr, float* ste_d_weight,
                   const float* ext_partial, int ext_count, int64_t ext_lo, int64_t ext_hi,
-                  nnue_stream_t stream);
+                  float* coef_out, int ext_applied_elsewhere, nnue_stream_t stream);
 
 /* ---- input pipeline ------------------------------------------------------------------------------
  * One batch of GenericVisionDataset.__getitem__ + collate (data/datasets.py:173-195, :358-372) from a uint8

@@ -97,6 +97,35 @@ struct BwwEpi {  // d_weight rows with a position of their own
   __device__ __forceinline__ void store(int m, int n, float v, float2, float, int) const { d_weight[(size_t)m * L1 + n] = v; }
 };
 
+// The weight gradient consumed where it is produced: clip_grad_norm_ + SGD(momentum, weight decay) (train.py:363-366,
+// :457-464) applied to the table rows in place, element by element exactly as sgd_apply_kernel does -- d_weight is never
+// written (268 MB written and read back per step at the 224x224 configuration).  The clip coefficient comes from the
+// device scalar the optimizer's norm pass left (its table part formed without the gradient: nnue_ftm_gram_sqnorm).
+struct BwwSgdEpi {
+  static constexpr bool kAU8 = true;
+  static constexpr bool kFusedL1 = false;
+  static constexpr bool kBPair = false;
+  static constexpr bool kSq = false;
+  static constexpr bool kRmw = true;  // read-modify-write epilogue: goes through LDS so that rows are touched as whole 16-byte runs
+  float* __restrict__ weight;    // table rows [0, direct), updated in place
+  float* __restrict__ momentum;  // matching momentum rows or NULL
+  const float* __restrict__ coef;  // clip coefficient (device scalar)
+  int L1;
+  float lr, mom, wd, scale;
+  int first_step;
+  __device__ __forceinline__ float2 col(int) const { return make_float2(coef[0] * scale, 0.f); }
+  __device__ __forceinline__ float pre(int m, int n) const { return weight[(size_t)m * L1 + n]; }
+  __device__ __forceinline__ void store(int m, int n, float v, float2 c, float w, int) const {
+    const size_t i = (size_t)m * L1 + n;
+    float gi = fmaf(wd, w, v * c.x);
+    if (momentum) {
+      gi = first_step ? gi : fmaf(mom, momentum[i], gi);
+      momentum[i] = gi;
+    }
+    weight[i] = w - lr * gi;
+  }
+};
+
 struct ValEpi {  // d_conv_out = acc where the position is active, else 0
   static constexpr bool kAU8 = false;
   static constexpr bool kFusedL1 = false;
@@ -320,6 +349,62 @@ __device__ __forceinline__ void store_tile(float* __restrict__ smem, const Epi& 
       if (lane == 0) smem[wave] = sqacc;
       __syncthreads();
       if (tid == 0) epi.sq[tile] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+    }
+  }
+}
+
+template <class Epi, class = void>
+struct is_rmw { static constexpr bool value = false; };
+template <class Epi>
+struct is_rmw<Epi, decltype((void)Epi::kRmw)> { static constexpr bool value = Epi::kRmw; };
+
+// Epilogue of a tile whose results update memory in place (BwwSgdEpi): the accumulators are 16 consecutive floats per
+// lane group and row -- 64-byte pieces, a poor shape for a read-modify-write of two 268 MB arrays -- so the tile goes
+// through LDS and every thread then owns whole float4 runs of a row: all of the tile's parameter and momentum loads are
+// issued before the first result is combined (64 KB in flight per workgroup at 128 x 64).
+template <int BM, int BN, class Epi>
+__device__ __forceinline__ void rmw_tile(float* __restrict__ smem, const Epi& epi, const f32x4 (&acc)[BM / 32][BN / 32], int M, int N,
+                                         int m_base, int n_base, int m0, int n0) {
+  constexpr int TM = BM / 32, TN = BN / 32, LD = BN + 4, PER = BM * BN / 4 / 256;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const float gs = epi.coef[0] * epi.scale;
+  float4 w[PER], mo[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int idx = tid + 256 * u, row = idx / (BN / 4), c4 = idx % (BN / 4);
+    const int m = m_base + row, n = n_base + 4 * c4;
+    const bool ok = m < M && n < N;
+    const size_t i = (size_t)m * epi.L1 + n;
+    w[u] = ok ? *reinterpret_cast<const float4*>(epi.weight + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    mo[u] = (ok && epi.momentum && !epi.first_step) ? *reinterpret_cast<const float4*>(epi.momentum + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) smem[(m0 + 16 * i + 4 * q + e) * LD + n0 + 16 * t + r] = acc[i][t][e];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int idx = tid + 256 * u, row = idx / (BN / 4), c4 = idx % (BN / 4);
+    const int m = m_base + row, n = n_base + 4 * c4;
+    if (m < M && n < N) {
+      const float4 v = *reinterpret_cast<const float4*>(smem + row * LD + 4 * c4);
+      const size_t i = (size_t)m * epi.L1 + n;
+      float4 g;  // the arithmetic of sgd_apply_kernel, element by element
+      g.x = fmaf(epi.wd, w[u].x, v.x * gs); g.y = fmaf(epi.wd, w[u].y, v.y * gs);
+      g.z = fmaf(epi.wd, w[u].z, v.z * gs); g.w = fmaf(epi.wd, w[u].w, v.w * gs);
+      if (epi.momentum) {
+        if (!epi.first_step) {
+          g.x = fmaf(epi.mom, mo[u].x, g.x); g.y = fmaf(epi.mom, mo[u].y, g.y);
+          g.z = fmaf(epi.mom, mo[u].z, g.z); g.w = fmaf(epi.mom, mo[u].w, g.w);
+        }
+        *reinterpret_cast<float4*>(epi.momentum + i) = g;
+      }
+      *reinterpret_cast<float4*>(epi.weight + i) = make_float4(w[u].x - epi.lr * g.x, w[u].y - epi.lr * g.y, w[u].z - epi.lr * g.z,
+                                                              w[u].w - epi.lr * g.w);
     }
   }
 }
@@ -630,6 +715,8 @@ __device__ __forceinline__ void gemm_tile_bf(unsigned char* __restrict__ smem, c
   }
   if constexpr (Epi::kFusedL1) {
     fused_l1_epilogue<BM>(epi, l1pre, reinterpret_cast<float*>(smem), acc, m_base, tile_n, m0, n0, r, q, wave, tid);
+  } else if constexpr (is_rmw<Epi>::value) {
+    rmw_tile<BM, BN, Epi>(reinterpret_cast<float*>(smem), epi, acc, M, N, m_base, n_base, m0, n0);
   } else {
     store_tile<BM, BN, Epi>(reinterpret_cast<float*>(smem), epi, acc, M, N, m_base, n_base, m0, n0, tile, ks);
   }
@@ -877,6 +964,135 @@ __global__ __launch_bounds__(256) void ftm_binarize_kernel(const float* __restri
       if (st) atomicAdd(&sink[b], (float)st);
     }
   }
+}
+
+// ---- ||A^T D||_F^2 without A^T D ---------------------------------------------------------------------------------
+// The squared norm of the table's weight gradient d_W = A^T D (A [B][direct] the binary map, D = d_out [B][L1]) is
+//   sum_{f,n} (sum_b A_bf D_bn)^2 = sum_{b,b'} (A A^T)_{bb'} (D D^T)_{bb'}
+// -- two B x B Gram matrices instead of the [direct][L1] gradient, which lets clip_grad_norm_ (train.py:363-366) know
+// its norm before that gradient exists, so the product that forms it can apply the update in its epilogue (BwwSgdEpi).
+// A A^T: counts of common active positions -- integers < 2^24, exact in f32 and in any order, so K slices add their
+// 128 x 128 tiles with float atomics into a matrix a zero-fill kernel clears first.
+__global__ __launch_bounds__(256) void gram_a_kernel(const uint8_t* __restrict__ bits, unsigned bytes, int B, int P, int direct, int klen,
+                                                     int tiles_b, float* __restrict__ G) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 128 * kBfK * 2];
+  unsigned char* __restrict__ Ms = smem;
+  unsigned char* __restrict__ Ns = smem + 128 * kBfK * 2;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(bits), 0, bytes, 0x00020000);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int tm = blockIdx.x / tiles_b, tn = blockIdx.x % tiles_b;
+  if (tn > tm) return;  // symmetric: the mirror tile is written from this one
+  const int m_base = tm * 128, n_base = tn * 128;
+  const int k_lo = blockIdx.y * klen, k_hi = (k_lo + klen < direct) ? k_lo + klen : direct;
+  const int m0 = (wave >> 1) * 64, n0 = (wave & 1) * 64;
+  u32x4 rm[4], rn[4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int g = tid + 256 * i, row = g >> 3, k = k0 + (g & 7) * 16;
+      rm[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (m_base + row) * P + k, 0, 0);
+      rn[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (n_base + row) * P + k, 0, 0);
+    }
+  };
+  auto put = [&](unsigned char* img, const u32x4& raw, int row, int c, int k) {  // bytes at k .. k+15, only those below direct count
+    u32x4 lo, hi;
+    unsigned w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int valid = direct - (k + 4 * j);
+      w[j] = valid >= 4 ? raw[j] : valid <= 0 ? 0u : (raw[j] & ((1u << (8 * valid)) - 1u));
+    }
+    unsigned a, b;
+    bytes_to_bf16(w[0], a, b); lo[0] = a; lo[1] = b;
+    bytes_to_bf16(w[1], a, b); lo[2] = a; lo[3] = b;
+    bytes_to_bf16(w[2], a, b); hi[0] = a; hi[1] = b;
+    bytes_to_bf16(w[3], a, b); hi[2] = a; hi[3] = b;
+    *reinterpret_cast<u32x4*>(img + bf_img(row, c)) = lo;
+    *reinterpret_cast<u32x4*>(img + bf_img(row, c + 1)) = hi;
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  fetch(k_lo);
+  for (int k0 = k_lo; k0 < k_hi; k0 += kBfK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int g = tid + 256 * i, row = g >> 3, c = (g & 7) * 2;
+      put(Ms, rm[i], row, c, k0 + (g & 7) * 16);
+      put(Ns, rn[i], row, c, k0 + (g & 7) * 16);
+    }
+    __syncthreads();
+    if (k0 + kBfK < k_hi) fetch(k0 + kBfK);
+#pragma unroll
+    for (int kb = 0; kb < kBfK / 32; ++kb) {
+      const int c = kb * 4 + q;
+      bf16x8 a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(Ms + bf_img(m0 + 16 * i + r, c));
+#pragma unroll
+      for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const bf16x8*>(Ns + bf_img(n0 + 16 * t + r, c));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m_base + m0 + 16 * i + 4 * q + e, n = n_base + n0 + 16 * t + r;
+        if (m < B && n < B && acc[i][t][e] != 0.0f) {
+          atomicAdd(&G[(size_t)m * B + n], acc[i][t][e]);
+          if (tn != tm) atomicAdd(&G[(size_t)n * B + m], acc[i][t][e]);
+        }
+      }
+}
+
+// sum_{b,b'} G_A[b][b'] (D D^T)[b][b'] = sum_{b,n} (G_A D)[b][n] D[b][n]: one wave per 16 x 16 tile of T = G_A D (f32 MFMA,
+// K = B), multiplied element-wise with the same tile of D and summed in float64 -> partial[tile].  Unlike D D^T this
+// splits over the L1 columns too (B/16 x L1/16 independent waves), and D D^T is never formed.
+__global__ __launch_bounds__(256) void gram_apply_kernel(const float* __restrict__ G, const float* __restrict__ D, int B, int L1,
+                                                         float* __restrict__ partial) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int tiles_m = (B + 15) / 16, tiles_n = (L1 + 15) / 16;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= tiles_m * tiles_n) return;
+  const int ti = tile / tiles_n, tj = tile % tiles_n;
+  const int row = ti * 16 + r, col = tj * 16 + r;
+  const float* __restrict__ ga = G + (size_t)(row < B ? row : 0) * B;  // A operand: G_A[row][k], k contiguous (B % 4 == 0 not needed: scalar tail)
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 8;  // k blocks of 4 whose loads are issued together
+  for (int k0 = 0; k0 < B; k0 += 4 * U) {
+    float a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + 4 * u + q;
+      const bool in = k < B;
+      a[u] = (in && row < B) ? ga[k] : 0.0f;
+      b[u] = (in && col < L1) ? D[(size_t)k * L1 + col] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int m = ti * 16 + 4 * q + e;
+    if (m < B && col < L1) s += (double)acc[e] * (double)D[(size_t)m * L1 + col];
+  }
+#pragma unroll
+  for (int sh = 32; sh >= 1; sh >>= 1) s += __shfl_xor(s, sh);
+  if (lane == 0) partial[tile] = (float)s;
 }
 
 // ---- launch policy -------------------------------------------------------------------------------------------
@@ -1257,3 +1473,65 @@ extern "C" int nnue_ftm_forward_l1(const uint8_t* bits, const float* sink, const
   return nnue_launch_status("nnue_ftm_forward_l1");
 }
 
+
+// ---- the table's weight gradient consumed in place (single rank + SGD; see BwwSgdEpi and the Gram kernels) ----------
+extern "C" int64_t nnue_ftm_gram_sq_count(int B, int L1) { return (B > 0 && L1 > 0) ? (int64_t)((B + 15) / 16) * ((L1 + 15) / 16) : 0; }
+
+extern "C" int nnue_ftm_gram_sqnorm(const uint8_t* bits, const float* d_out, int B, int F, int P, int L1, float* gram, float* sq_partial,
+                                    nnue_stream_t stream) {
+  NNUE_REQUIRE(bits && d_out && gram && sq_partial, NNUE_E_ARG, "nnue_ftm_gram_sqnorm: null pointer");
+  NNUE_REQUIRE(shape_ok(B, F, P, L1), NNUE_E_ARG, "nnue_ftm_gram_sqnorm: B=%d F=%d P=%d L1=%d out of range", B, F, P, L1);
+  NNUE_REQUIRE(nnue_ftm_supported(F, P, L1), NNUE_E_SHAPE, "nnue_ftm_gram_sqnorm: P=%d and L1=%d must be multiples of 4", P, L1);
+  NNUE_REQUIRE(nnue_ftm_gram_sq_count(B, L1) <= 65536, NNUE_E_SHAPE, "nnue_ftm_gram_sqnorm: B=%d x L1=%d gives more than 65536 partials", B, L1);
+  NNUE_REQUIRE(nnue_aligned16(bits) && nnue_aligned16(d_out), NNUE_E_ARG, "nnue_ftm_gram_sqnorm: pointers must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int direct = (F - 1 < P) ? F - 1 : P;
+  const int tiles_b = (B + 127) / 128, lower = tiles_b * (tiles_b + 1) / 2;
+  const int ktiles = (direct + kBfK - 1) / kBfK;
+  nnue_zero_floats(gram, (size_t)B * B, st);
+  if (direct > 0) {
+    int slices = 128 / lower;
+    slices = slices < 1 ? 1 : (slices > ktiles ? ktiles : slices);
+    const int per = (ktiles + slices - 1) / slices;
+    slices = (ktiles + per - 1) / per;
+    hipLaunchKernelGGL(gram_a_kernel, dim3((unsigned)(tiles_b * tiles_b), (unsigned)slices), dim3(256), 0, st, bits, (unsigned)((size_t)B * P), B, P,
+                       direct, per * kBfK, tiles_b, gram);
+  }
+  const int64_t tiles16 = nnue_ftm_gram_sq_count(B, L1);
+  hipLaunchKernelGGL(gram_apply_kernel, dim3((unsigned)((tiles16 + 3) / 4)), dim3(256), 0, st, gram, d_out, B, L1, sq_partial);
+  return nnue_launch_status("nnue_ftm_gram_sqnorm");
+}
+
+extern "C" int nnue_ftm_backward_tail_rows(const float* sink, const float* d_out, int B, int F, int P, int L1, float* d_weight, float* d_bias,
+                                           nnue_stream_t stream) {
+  NNUE_REQUIRE(sink && d_out && (d_weight || d_bias), NNUE_E_ARG, "nnue_ftm_backward_tail_rows: null pointer");
+  NNUE_REQUIRE(shape_ok(B, F, P, L1), NNUE_E_ARG, "nnue_ftm_backward_tail_rows: B=%d F=%d P=%d L1=%d out of range", B, F, P, L1);
+  const int direct = (F - 1 < P) ? F - 1 : P;
+  const TailRows t = tail_rows(d_out, sink, B, L1, direct, F, d_weight, d_bias);
+  hipLaunchKernelGGL(ftm_tail_rows_kernel, dim3(t.col_blocks, 1 + t.zero_slices), dim3(256), 0, static_cast<hipStream_t>(stream), t);
+  return nnue_launch_status("nnue_ftm_backward_tail_rows");
+}
+
+extern "C" int nnue_ftm_backward_weight_update(const uint8_t* bits, const float* d_out, int B, int F, int P, int L1, float* weight,
+                                               float* momentum_rows, const float* coef, float lr, float momentum, float weight_decay,
+                                               float grad_scale, int first_step, nnue_stream_t stream) {
+  NNUE_REQUIRE(bits && d_out && weight && coef, NNUE_E_ARG, "nnue_ftm_backward_weight_update: null pointer");
+  NNUE_REQUIRE(momentum == 0.0f || momentum_rows, NNUE_E_ARG, "nnue_ftm_backward_weight_update: momentum %g needs the momentum rows", momentum);
+  NNUE_REQUIRE(shape_ok(B, F, P, L1), NNUE_E_ARG, "nnue_ftm_backward_weight_update: B=%d F=%d P=%d L1=%d out of range", B, F, P, L1);
+  NNUE_REQUIRE(nnue_ftm_supported(F, P, L1), NNUE_E_SHAPE, "nnue_ftm_backward_weight_update: P=%d and L1=%d must be multiples of 4", P, L1);
+  NNUE_REQUIRE(nnue_aligned16(bits) && nnue_aligned16(d_out) && nnue_aligned16(weight), NNUE_E_ARG,
+               "nnue_ftm_backward_weight_update: pointers must be 16-byte aligned");
+  const int direct = (F - 1 < P) ? F - 1 : P;
+  if (direct <= 0) return NNUE_OK;
+  Shape s = plan(direct, L1, B, false, false, true);
+  if (s.cfg < 6) {  // launch-sized product: a 64-row bf16 tile (the in-place epilogue lives in the bf16 tile)
+    s.cfg = 7; s.bm = 64; s.bn = 64; s.bk = kBfK;
+    s.tiles_m = (direct + 63) / 64; s.tiles_n = (L1 + 63) / 64; s.ksplit = 1; s.klen = (B + kBfK - 1) / kBfK * kBfK;
+  }
+  NNUE_REQUIRE(s.ksplit == 1, NNUE_E_SHAPE, "nnue_ftm_backward_weight_update: the product must not be split along K");
+  launch<false, false>(static_cast<hipStream_t>(stream), s, Mat{bits, (unsigned)((size_t)B * P), P, kIntMax, kIntMax},
+                       Mat{d_out, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, kIntMax},
+                       BwwSgdEpi{weight, momentum == 0.0f ? nullptr : momentum_rows, coef, L1, lr, momentum, weight_decay, grad_scale, first_step},
+                       direct, L1, B);
+  return nnue_launch_status("nnue_ftm_backward_weight_update");
+}

@@ -183,11 +183,11 @@ __global__ __launch_bounds__(256) void sgd_apply_kernel(float* __restrict__ p, c
                                                         float wd, float max_norm, float scale, int first_step,
                                                         const float* __restrict__ partial, int nparts,
                                                         float* __restrict__ norm_out, const float* __restrict__ ext_partial,
-                                                        int ext_count) {
+                                                        int ext_count, float* __restrict__ coef_out, int64_t skip_lo, int64_t skip_hi) {
   __shared__ double red[4];
   __shared__ float coef_s;
   float clip = 1.0f;
-  if (max_norm > 0.0f || norm_out) {
+  if (max_norm > 0.0f || norm_out || coef_out) {
     double acc = 0.0;
     for (int i = threadIdx.x; i < nparts; i += 256) acc += (double)partial[i];
     if (ext_partial) {  // a producer's sums of squares (unscaled) of the range the norm launch skipped
@@ -202,13 +202,16 @@ __global__ __launch_bounds__(256) void sgd_apply_kernel(float* __restrict__ p, c
       const float norm = (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
       if (norm_out && blockIdx.x == 0) *norm_out = norm;
       coef_s = max_norm > 0.0f ? fminf(max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+      if (coef_out && blockIdx.x == 0) *coef_out = coef_s;  // for the producer that applies [skip_lo, skip_hi) itself
     }
     __syncthreads();
     clip = coef_s;
   }
   const float gs = clip * scale;
   const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+  const int64_t hole = skip_hi - skip_lo;  // 0: everything is updated here
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < count - hole; j += stride) {
+    const int64_t i = j < skip_lo ? j : j + hole;
     const float w = p[i];
     float gi = fmaf(wd, w, g[i] * gs);
     if (m) {
@@ -310,7 +313,7 @@ extern "C" int nnue_sgd_step(float* params, float* grads, float* momentum_buf, i
                              float weight_decay, float max_norm, float grad_scale, int first_step, float* norm_out,
                              void* scratch, int64_t scratch_bytes, const float* ste_partial, int ste_chunks, int ste_fps,
                              float* ste_d_thr, float* ste_d_weight, const float* ext_partial, int ext_count, int64_t ext_lo,
-                             int64_t ext_hi, nnue_stream_t stream) {
+                             int64_t ext_hi, float* coef_out, int ext_applied_elsewhere, nnue_stream_t stream) {
   NNUE_REQUIRE(params && grads && scratch, NNUE_E_ARG, "nnue_sgd_step: null pointer");
   NNUE_REQUIRE(count > 0, NNUE_E_ARG, "nnue_sgd_step: count must be positive");
   NNUE_REQUIRE(momentum == 0.0f || momentum_buf, NNUE_E_ARG, "nnue_sgd_step: momentum %g needs a momentum buffer", momentum);
@@ -347,13 +350,18 @@ extern "C" int nnue_sgd_step(float* params, float* grads, float* momentum_buf, i
     hipLaunchKernelGGL(sqnorm_stage1_ste, dim3(nb + s2_blocks), dim3(256), 0, s, grads, count, grad_scale, partial, ste_partial,
                        ste_chunks, ste_fps, ste_d_thr, ste_d_weight, s2_blocks, skip, ext_lo, ext_hi, nb);
     nparts = nb + s2_blocks;
-  } else if (max_norm > 0.0f || norm_out) {
+  } else if (max_norm > 0.0f || norm_out || coef_out) {
     hipLaunchKernelGGL(sqnorm_stage1, dim3(nb), dim3(256), 0, s, grads, count, grad_scale, partial, ext_lo, ext_hi);
   }
-  int blocks = (int)((count + 1023) / 1024);
+  NNUE_REQUIRE(!ext_applied_elsewhere || (ext_partial && coef_out), NNUE_E_ARG,
+               "nnue_sgd_step: ext_applied_elsewhere needs the producer's partials and coef_out");
+  const int64_t live = ext_applied_elsewhere ? count - (ext_hi - ext_lo) : count;
+  int blocks = (int)((live + 1023) / 1024);
+  blocks = blocks < 1 ? 1 : blocks;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(sgd_apply_kernel, dim3(blocks), dim3(256), 0, s, params, grads, momentum == 0.0f ? nullptr : momentum_buf,
-                     count, lr, momentum, weight_decay, max_norm, grad_scale, first_step, partial, nparts, norm_out, ext_partial, ext_count);
+                     count, lr, momentum, weight_decay, max_norm, grad_scale, first_step, partial, nparts, norm_out, ext_partial, ext_count,
+                     coef_out, ext_applied_elsewhere ? ext_lo : (int64_t)0, ext_applied_elsewhere ? ext_hi : (int64_t)0);
   return nnue_launch_status("nnue_sgd_step");
 }
 

@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -112,7 +112,12 @@ SIGNATURES = {
     "nnue_adam_step": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f,
                                 _c_p, _c_p, _c_i64, _c_p]),
     "nnue_sgd_step": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_int,
-                               _c_p, _c_p, _c_i64, _c_p, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_i64, _c_i64, _c_p]),
+                               _c_p, _c_p, _c_i64, _c_p, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_i64, _c_i64, _c_p, _c_int, _c_p]),
+    "nnue_ftm_gram_sq_count": (_c_i64, [_c_int, _c_int]),
+    "nnue_ftm_gram_sqnorm": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
+    "nnue_ftm_backward_tail_rows": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
+    "nnue_ftm_backward_weight_update": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_f, _c_f, _c_f, _c_f,
+                                                 _c_int, _c_p]),
 }
 
 _lib: Optional[ctypes.CDLL] = None
@@ -929,9 +934,41 @@ def sgd_scratch_bytes(count: int) -> int:
     return int(load().nnue_sgd_scratch(count))
 
 
+def ftm_gram_sqnorm(fm: "FeatureMatrix", d_out: torch.Tensor, gram: torch.Tensor, sq_partial: torch.Tensor) -> torch.Tensor:
+    """Partial sums of ||A^T d_out||_F^2 over the table rows the map reaches, from two B x B Gram matrices."""
+    d_out = _need(d_out, torch.float32, "d_out")
+    b, l1 = d_out.shape
+    _need(gram, torch.float32, "gram", (b, b))
+    _need(sq_partial, torch.float32, "gram partials", (int(load().nnue_ftm_gram_sq_count(b, l1)),))
+    _call("nnue_ftm_gram_sqnorm", fm.bits.data_ptr(), d_out.data_ptr(), b, fm.num_rows, fm.positions, l1, gram.data_ptr(),
+          sq_partial.data_ptr(), _stream(d_out))
+    return sq_partial
+
+
+def ftm_backward_tail_rows(d_out: torch.Tensor, fm: "FeatureMatrix", d_weight: torch.Tensor, d_bias: torch.Tensor) -> None:
+    d_out = _need(d_out, torch.float32, "d_out")
+    b, l1 = d_out.shape
+    _call("nnue_ftm_backward_tail_rows", fm.sink.data_ptr(), d_out.data_ptr(), b, fm.num_rows, fm.positions, l1, d_weight.data_ptr(),
+          d_bias.data_ptr(), _stream(d_out))
+
+
+def ftm_backward_weight_update(d_out: torch.Tensor, fm: "FeatureMatrix", weight: torch.Tensor, momentum_rows: Optional[torch.Tensor],
+                               coef: torch.Tensor, lr: float, momentum: float, weight_decay: float, grad_scale: float,
+                               first_step: bool) -> None:
+    """weight rows [0, direct) <- SGD update with d_W = A^T d_out formed and consumed in the product's epilogue."""
+    d_out = _need(d_out, torch.float32, "d_out")
+    b, l1 = d_out.shape
+    weight = _need(weight, torch.float32, "input.weight", (fm.num_rows, l1))
+    _need(coef, torch.float32, "clip coefficient")
+    _call("nnue_ftm_backward_weight_update", fm.bits.data_ptr(), d_out.data_ptr(), b, fm.num_rows, fm.positions, l1, weight.data_ptr(),
+          _ptr(momentum_rows), coef.data_ptr(), float(lr), float(momentum), float(weight_decay), float(grad_scale),
+          int(bool(first_step)), _stream(d_out))
+
+
 def sgd_step(params: torch.Tensor, grads: torch.Tensor, momentum_buf: Optional[torch.Tensor], lr: float,
              momentum: float, weight_decay: float, max_norm: float, grad_scale: float, first_step: bool,
-             norm_out: Optional[torch.Tensor], scratch: torch.Tensor, ste=None, ext=None) -> None:
+             norm_out: Optional[torch.Tensor], scratch: torch.Tensor, ste=None, ext=None,
+             coef_out: Optional[torch.Tensor] = None, ext_applied_elsewhere: bool = False) -> None:
     """ste = (partial scratch of ste_conv_backward(stages=1), chunks, fps, d_thr, d_weight): the deferred second stage
     runs inside the norm launch; d_thr / d_weight must be the first elements of `grads`."""
     params = _need(params, torch.float32, "flat params")
@@ -947,7 +984,8 @@ def sgd_step(params: torch.Tensor, grads: torch.Tensor, momentum_buf: Optional[t
     ext_args = (ext[0].data_ptr(), ext[0].numel(), int(ext[1]), int(ext[2])) if ext is not None else (None, 0, 0, 0)
     _call("nnue_sgd_step", params.data_ptr(), grads.data_ptr(), _ptr(momentum_buf), params.numel(), float(lr),
           float(momentum), float(weight_decay), float(max_norm), float(grad_scale), int(bool(first_step)),
-          _ptr(norm_out), scratch.data_ptr(), scratch.numel(), *ste_args, *ext_args, _stream(params))
+          _ptr(norm_out), scratch.data_ptr(), scratch.numel(), *ste_args, *ext_args, _ptr(coef_out), int(bool(ext_applied_elsewhere)),
+          _stream(params))
 
 
 def adam_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,

@@ -227,6 +227,24 @@ class NnueTrainer:
             if off % 4 == 0 and (rows * self.L1) % 4 == 0:
                 self.sq_partial = torch.empty((n_sq,), **f32)
                 self.sq_range = (off, off + rows * self.L1)
+        # Big tables on a single rank with SGD: the FeatureTransformer weight gradient is never materialised.  Its squared
+        # norm comes from two B x B Gram matrices (nnue_ftm_gram_sqnorm), the optimizer's norm/apply pass skips those rows
+        # and leaves the clip coefficient in a device scalar, and the product d_W = A^T d_out runs LAST, applying the update
+        # to the table in its epilogue (nnue_ftm_backward_weight_update): no 268 MB write + read at the 224x224 shape.
+        self.fuse_table_update = False
+        rows = min(self.F - 1, self.P)
+        off = self.layout.offsets[self.layout.names.index("input.weight")]
+        big_table = self.F * self.L1 * 4 >= (32 << 20)
+        want = os.environ.get("NNUE_FUSE_TABLE_UPDATE", "auto")
+        if (self.use_mfma and not self.dp.collectives and optimizer == "sgd" and rows > 0 and B * self.L1 <= (1 << 24) and off % 4 == 0
+                and (rows * self.L1) % 4 == 0 and want != "0" and (big_table or want == "1")):
+            self.fuse_table_update = True
+            self.ride_dw1 = False  # the rider lives in the merged launch, which this path does not use
+            self.sq_partial = torch.empty((int(lib.load().nnue_ftm_gram_sq_count(B, self.L1)),), **f32)
+            self.sq_range = (off, off + rows * self.L1)
+            self.gram = torch.zeros((B, B), **f32)
+            self.clip_coef = torch.ones((), **f32)
+        self.grads_materialised = not self.fuse_table_update
         self.d_z1 = self.ft_rider = None
         if self.ride_dw1 and self.K == 1:
             off = lib.classifier_train_dz1_offset(B, self.L1, self.L2, self.L3, self.C, True)
@@ -319,7 +337,12 @@ class NnueTrainer:
                 lib.ft_forward(p["input.weight"], p["input.bias"], self.act, out=self.ft)
             self._cls_step(19 if self.ride_dw1 else 5)  # 5: + the first-layer weight product beside d_x
         elif name == "ft_wgrad":
-            if self.use_mfma and self.merge_backward:
+            if self.fuse_table_update:
+                # rows the product does not cover (bias, clamp-sink row, unreachable rows) + the Gram form of the norm;
+                # the product itself is part of the update (_update)
+                lib.ftm_backward_tail_rows(self.d_ft, self.fm, g["input.weight"], g["input.bias"])
+                lib.ftm_gram_sqnorm(self.fm, self.d_ft, self.gram, self.sq_partial)
+            elif self.use_mfma and self.merge_backward:
                 # weight gradient, value gradient and tail rows share one launch (independent work, all read d_ft)
                 lib.ftm_backward(self.d_ft, p["input.weight"], self.fm, d_weight=g["input.weight"], d_bias=g["input.bias"],
                                  dst=self.d_conv_out, ft=self.ft_rider, d_z1=self.d_z1,
@@ -335,7 +358,7 @@ class NnueTrainer:
             if not self.ride_dw1:  # else the small gradients already rode in the d_x launch of "forward"
                 self._cls_step(6)
         elif name == "tail":
-            if self.use_mfma and self.merge_backward:
+            if self.use_mfma and self.merge_backward and not self.fuse_table_update:
                 pass  # d_conv_out came out of the merged launch in "ft_wgrad"
             elif self.use_mfma:
                 lib.ftm_backward_values(self.d_ft, p["input.weight"], self.fm, dst=self.d_conv_out)
@@ -369,7 +392,14 @@ class NnueTrainer:
                    if self.defer_ste else None)
             lib.sgd_step(self.flat_params, self.flat_grads, self.flat_momentum, self.lr, self.momentum, self.weight_decay,
                          self.max_grad_norm, scale, first, self.grad_norm, self.sgd_scratch, ste=ste,
-                         ext=(self.sq_partial, *self.sq_range) if self.sq_partial is not None else None)
+                         ext=(self.sq_partial, *self.sq_range) if self.sq_partial is not None else None,
+                         coef_out=self.clip_coef if self.fuse_table_update else None,
+                         ext_applied_elsewhere=self.fuse_table_update)
+            if self.fuse_table_update:
+                lo, hi = self.sq_range
+                mom = self.flat_momentum[lo:hi] if self.flat_momentum is not None else None
+                lib.ftm_backward_weight_update(self.d_ft, self.fm, self.p["input.weight"], mom, self.clip_coef, self.lr, self.momentum,
+                                               self.weight_decay, scale, first)
 
     def _optimizer_buffers(self):
         return [t for t in (self.flat_momentum, self.flat_exp_avg, self.flat_exp_avg_sq, self.adam_step_count) if t is not None]

@@ -135,9 +135,14 @@ def test_ftm_argument_errors(hip):
 
 @pytest.mark.parametrize("shape", [(512, 8, 11, 11, 800, 1024), (1024, 8, 11, 11, 800, 1024), (128, 64, 32, 32, 65536, 1024),
                                    (37, 4, 8, 8, 256, 64), (5, 4, 3, 3, 100, 36)])
-def test_merged_backward_is_bitwise_the_two_launches(hip, shape):
+@pytest.mark.parametrize("bf16", ("0", "1"))
+def test_merged_backward_is_bitwise_the_two_launches(hip, shape, bf16, monkeypatch):
     """nnue_ftm_backward (one launch) against nnue_ftm_backward_weight + nnue_ftm_backward_values: every tile-shape pair
-    the policy picks for the BASELINE configurations, and shapes that fall back to the two launches."""
+    the policy picks for the BASELINE configurations, and shapes that fall back to the two launches.  With the f32 tiles
+    (NNUE_FTM_BF16=0) the merged launch runs the very tiles of the separate launches -- bitwise equal; with the bf16-split
+    tiles the merged launch may take another tile height for the weight gradient than the stand-alone call (another
+    summation order of the same exact terms): equal to rounding."""
+    monkeypatch.setenv("NNUE_FTM_BF16", bf16)
     b, fps, gh, gw, f, l1 = shape
     gen = torch.Generator().manual_seed(f + b)
     conv_out = torch.randn(b, fps, gh, gw, generator=gen).to(DEV)
@@ -148,7 +153,11 @@ def test_merged_backward_is_bitwise_the_two_launches(hip, shape):
     d_w, d_b = hip.ftm_backward_weight(d_out, fm)
     d_v = hip.ftm_backward_values(d_out, weight, fm)
     m_w, m_b, m_v = hip.ftm_backward(d_out, weight, fm)
-    assert torch.equal(m_w, d_w) and torch.equal(m_b, d_b) and torch.equal(m_v, d_v)
+    assert torch.equal(m_b, d_b) and torch.equal(m_v, d_v)
+    if bf16 == "0":
+        assert torch.equal(m_w, d_w)
+    else:
+        assert_close_grad(m_w, d_w, "d_weight, merged vs stand-alone", rtol=2e-6)
 
 
 @pytest.mark.parametrize("shape", [(512, 32, 32, 8, 3, 800), (128, 224, 224, 64, 7, 65536), (5, 17, 23, 4, 2, 300), (3, 96, 96, 8, 10, 800),
@@ -198,7 +207,8 @@ def test_random_shapes_sweep(hip):
         assert_close_grad(d_b, ref_db, f"d_bias {tag}", rtol=2e-5)
         assert_close_grad(d_v.view(conv_out.shape), ref_dval, f"d_conv_out {tag}", rtol=2e-5)
         s_w, s_b = hip.ftm_backward_weight(g(d_out), fm)
-        assert torch.equal(s_w, d_w) and torch.equal(s_b, d_b) and torch.equal(hip.ftm_backward_values(g(d_out), g(weight), fm), d_v), tag
+        assert torch.equal(s_b, d_b) and torch.equal(hip.ftm_backward_values(g(d_out), g(weight), fm), d_v), tag
+        assert_close_grad(s_w, d_w, f"d_weight merged vs stand-alone {tag}", rtol=2e-6)  # the merged launch may take bf16-split tiles
         done += 1
 
 
@@ -302,3 +312,51 @@ def test_weight_gradient_tiles_leave_their_squared_norm(hip, shape):
         outs.append((pp, float(norm)))
     assert abs(outs[0][1] - outs[1][1]) <= 1e-5 * outs[0][1]
     assert_close_grad(outs[1][0], outs[0][0], "updated parameters", rtol=1e-5)
+
+
+@pytest.mark.parametrize("shape", ((128, 64, 32, 32, 65536, 1024), (5, 4, 3, 3, 100, 36), (200, 8, 11, 11, 800, 256), (300, 8, 10, 10, 800, 64),
+                                   (37, 4, 8, 8, 200, 64)))
+def test_gram_form_of_the_weight_gradient_norm(hip, shape):
+    """||A^T D||_F^2 = sum (A A^T) . (D D^T) over the table rows the map reaches (nnue_ftm_gram_sqnorm), against the
+    float64 norm of the materialised gradient."""
+    b, fps, gh, gw, f, l1 = shape
+    gen = torch.Generator().manual_seed(b + f)
+    conv_out = torch.randn(b, fps, gh, gw, generator=gen)
+    thr = torch.full((fps,), 0.17)
+    d_out = torch.randn(b, l1, generator=gen) / b + 0.3 / b  # a common component: off-diagonal Gram terms matter
+    fm = hip.ftm_binarize(conv_out.to(DEV), thr.to(DEV), f, l1)
+    direct = min(f - 1, fps * gh * gw)
+    a = (conv_out > 0.17).reshape(b, -1)[:, :direct].double()
+    ref = float(((a.t() @ d_out.double()) ** 2).sum())
+    gram = torch.zeros(b, b, device=DEV)
+    part = torch.empty(int(hip.load().nnue_ftm_gram_sq_count(b, l1)), device=DEV)
+    for _ in range(2):  # the scratch is cleared by the call itself
+        hip.ftm_gram_sqnorm(fm, d_out.to(DEV), gram, part)
+        got = float(part.double().sum())
+        assert abs(got - ref) <= 2e-6 * ref, (got, ref)
+    assert torch.equal(gram.cpu().double(), a @ a.t())  # common active positions: exact integers
+
+
+def test_table_update_in_the_product_epilogue_equals_the_materialised_path(hip, monkeypatch):
+    """NNUE_FUSE_TABLE_UPDATE: Gram norm + optimizer pass that skips the table + product with the SGD epilogue, against the
+    path that writes d_weight and reads it back -- three steps with momentum, weight decay and an active clip."""
+    import nnue
+    from nnue_hip.trainer import NnueTrainer
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NNUE_FUSE_TABLE_UPDATE", mode)
+        torch.manual_seed(4)
+        model = nnue.NNUE(nnue.GridFeatureSet(16, 16), 256, 32, 16, num_classes=10, input_size=64).to(DEV)
+        tr = NnueTrainer(model, 96, (64, 64), lr=0.05, momentum=0.9, weight_decay=1e-3, max_grad_norm=0.5, use_graph=True)
+        assert tr.fuse_table_update == (mode == "1") and tr.grads_materialised == (mode == "0")
+        gen = torch.Generator().manual_seed(8)
+        norms = []
+        for _ in range(3):
+            images, labels = torch.randn(96, 3, 64, 64, generator=gen), torch.randint(0, 10, (96,), generator=gen)
+            tr.step(images.to(DEV), labels.to(DEV))
+            norms.append(float(tr.grad_norm))
+        runs[mode] = (norms, tr.flat_params.clone(), tr.flat_momentum.clone())
+    for a, b in zip(runs["1"][0], runs["0"][0]):
+        assert abs(a - b) <= 2e-6 * b and b > 0.5  # the clip is active
+    assert_close_grad(runs["1"][1], runs["0"][1], "parameters", rtol=1e-6)
+    assert_close_grad(runs["1"][2], runs["0"][2], "momentum", rtol=1e-5)
