@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 21
+#define NNUE_HIP_ABI_VERSION 22
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -465,6 +465,11 @@ int64_t nnue_engine_scratch(const nnue_engine_model* m, int B);
 int nnue_engine_evaluate_logits(const nnue_engine_model* m, const float* images, int B, int H, int W,
                                 float* logits, float* density, void* scratch, int64_t scratch_bytes,
                                 nnue_stream_t stream);
+
+/* The first stage of the clip norm below, alone: nparts block partials of sum g^2 (unscaled, fixed order) -- what a rank contributes
+ * when the clip norm of clip_grad_norm_ (train.py:363-364) spans gradient shards held by different ranks: the partials are
+ * all-gathered and handed to every rank's nnue_sgd_step as ext_partial over its whole shard. */
+int nnue_sqnorm_partials(const float* grads, int64_t count, float* partial, int nparts, nnue_stream_t stream);
 
 /* clip_grad_norm_ + SGD(momentum, weight_decay) on flat buffers (train.py:363-366, :457-464):
  *   g <- g * grad_scale              (1/world after a summed all-reduce)

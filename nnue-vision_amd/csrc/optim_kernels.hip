@@ -309,6 +309,15 @@ extern "C" int64_t nnue_sgd_scratch(int64_t count) {
   return (kNormBlocks + kSteRideBlocks) * (int64_t)sizeof(float);
 }
 
+extern "C" int nnue_sqnorm_partials(const float* grads, int64_t count, float* partial, int nparts, nnue_stream_t stream) {
+  NNUE_REQUIRE(grads && partial, NNUE_E_ARG, "nnue_sqnorm_partials: null pointer");
+  NNUE_REQUIRE(count > 0 && nparts > 0 && nparts <= 65536, NNUE_E_ARG, "nnue_sqnorm_partials: count=%lld nparts=%d out of range",
+               (long long)count, nparts);
+  hipLaunchKernelGGL(sqnorm_stage1, dim3(nparts), dim3(256), 0, static_cast<hipStream_t>(stream), grads, count, 1.0f, partial, (int64_t)0,
+                     (int64_t)0);
+  return nnue_launch_status("nnue_sqnorm_partials");
+}
+
 extern "C" int nnue_sgd_step(float* params, float* grads, float* momentum_buf, int64_t count, float lr, float momentum,
                              float weight_decay, float max_norm, float grad_scale, int first_step, float* norm_out,
                              void* scratch, int64_t scratch_bytes, const float* ste_partial, int ste_chunks, int ste_fps,
@@ -327,7 +336,8 @@ extern "C" int nnue_sgd_step(float* params, float* grads, float* momentum_buf, i
   nb = nb < 64 ? 64 : (nb > kNormBlocks ? kNormBlocks : nb);
   int nparts = nb;
   if (ext_partial) {
-    NNUE_REQUIRE(ext_count > 0 && ext_count <= 65536 && ext_lo >= 0 && ext_lo < ext_hi && ext_hi <= count && ext_lo % 4 == 0 && ext_hi % 4 == 0,
+    NNUE_REQUIRE(ext_count > 0 && ext_count <= 65536 && ext_lo >= 0 && ext_lo < ext_hi && ext_hi <= count && ext_lo % 4 == 0 &&
+                     (ext_hi % 4 == 0 || ext_hi == count),
                  NNUE_E_ARG, "nnue_sgd_step: producer partials need 0 < count <= 65536 and a range [lo, hi) of multiples of 4 inside grads");
   } else {
     ext_lo = ext_hi = 0;

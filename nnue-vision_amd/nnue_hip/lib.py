@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -113,6 +113,7 @@ SIGNATURES = {
                                 _c_p, _c_p, _c_i64, _c_p]),
     "nnue_sgd_step": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_int,
                                _c_p, _c_p, _c_i64, _c_p, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_i64, _c_i64, _c_p, _c_int, _c_p]),
+    "nnue_sqnorm_partials": (_c_int, [_c_p, _c_i64, _c_p, _c_int, _c_p]),
     "nnue_ftm_gram_sq_count": (_c_i64, [_c_int, _c_int]),
     "nnue_ftm_gram_sqnorm": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
     "nnue_ftm_backward_tail_rows": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
@@ -932,6 +933,14 @@ def confusion_accumulate(logits: torch.Tensor, labels: torch.Tensor, confusion: 
 
 def sgd_scratch_bytes(count: int) -> int:
     return int(load().nnue_sgd_scratch(count))
+
+
+def sqnorm_partials(grads: torch.Tensor, partial: torch.Tensor) -> torch.Tensor:
+    """partial[i] = block partial sums of grads^2 (their sum is ||grads||^2); fixed order."""
+    grads = _need(grads, torch.float32, "gradient shard")
+    _need(partial, torch.float32, "partials")
+    _call("nnue_sqnorm_partials", grads.data_ptr(), grads.numel(), partial.data_ptr(), partial.numel(), _stream(grads))
+    return partial
 
 
 def ftm_gram_sqnorm(fm: "FeatureMatrix", d_out: torch.Tensor, gram: torch.Tensor, sq_partial: torch.Tensor) -> torch.Tensor:

@@ -48,7 +48,8 @@ class FlatLayout:
     count: int  # padded element count of the flat buffers
 
     @staticmethod
-    def of(model: torch.nn.Module, align: int = 4) -> "FlatLayout":
+    def of(model: torch.nn.Module, align: int = 4, pad_to: int = 1) -> "FlatLayout":
+        """pad_to: the flat buffers' length becomes a multiple of it (equal, float4-aligned shards per rank)."""
         names, shapes, offsets, off = [], [], [], 0
         for k, p in model.named_parameters():
             if k in SKIP:
@@ -57,7 +58,7 @@ class FlatLayout:
             shapes.append(tuple(p.shape))
             offsets.append(off)
             off += (p.numel() + align - 1) // align * align  # 16-byte aligned starts for the float4 kernels
-        return FlatLayout(names, shapes, offsets, off)
+        return FlatLayout(names, shapes, offsets, (off + pad_to - 1) // pad_to * pad_to)
 
     def views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
         out = {}
@@ -89,6 +90,7 @@ class DataParallel:
         # RCCL + hipGraph interplay on a single-GPU box; a 1-rank all-reduce is the identity)
         self.collectives = self.enabled and (self.world > 1 or os.environ.get("NNUE_DP_FORCE_COLLECTIVES") == "1")
         self.buckets = 2 if os.environ.get("NNUE_DP_BUCKETS", "1") == "2" else 1
+        self.backend = dist.get_backend(group) if self.enabled else None
 
     @property
     def grad_scale(self) -> float:
@@ -108,6 +110,37 @@ class DataParallel:
         if self.collectives:
             return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         return None
+
+    # ---- sharded update (reduce-scatter the gradient, update one shard per rank, all-gather the parameters): the same
+    # wire bytes as the all-reduce, 1/world of the optimizer's memory traffic per rank -- for flat buffers that are
+    # bandwidth- rather than latency-sized (the 269 MB of the 224x224 configuration)
+    def shard_of(self, flat: torch.Tensor) -> torch.Tensor:
+        per = flat.numel() // self.world
+        if per * self.world != flat.numel():
+            raise ValueError("flat buffer length must be a multiple of the world size (FlatLayout.of(pad_to=...))")
+        return flat[self.rank * per:(self.rank + 1) * per]
+
+    def reduce_scatter_sum(self, flat: torch.Tensor, out_shard: torch.Tensor) -> None:
+        """out_shard <- this rank's shard of the sum over ranks of `flat`."""
+        if not self.collectives:
+            out_shard.copy_(self.shard_of(flat))
+        elif self.backend == "nccl":
+            dist.reduce_scatter_tensor(out_shard, flat, op=dist.ReduceOp.SUM, group=self.group)
+        else:  # gloo has no reduce-scatter: all-reduce, keep the own slice (CPU tests / rehearsals only)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            out_shard.copy_(self.shard_of(flat))
+
+    def all_gather(self, flat_out: torch.Tensor, shard: torch.Tensor) -> None:
+        """flat_out <- the ranks' shards side by side (shard may be flat_out's own slice)."""
+        if not self.collectives:
+            if shard.data_ptr() != self.shard_of(flat_out).data_ptr():
+                self.shard_of(flat_out).copy_(shard)
+        elif self.backend == "nccl":
+            dist.all_gather_into_tensor(flat_out, shard, group=self.group)
+        else:
+            per = flat_out.numel() // self.world
+            parts = [flat_out[r * per:(r + 1) * per] for r in range(self.world)]
+            dist.all_gather(parts, shard.clone(), group=self.group)
 
 
 class NnueTrainer:
@@ -139,7 +172,7 @@ class NnueTrainer:
         self.P = self.fps * self.gh * self.gw
 
         # ---- flat parameter / gradient / momentum buffers; module parameters become views
-        self.layout = FlatLayout.of(model)
+        self.layout = FlatLayout.of(model, pad_to=4 * self.dp.world)
         f32 = dict(dtype=torch.float32, device=self.dev)
         state = {k: p.detach() for k, p in model.named_parameters() if k not in SKIP}
         self.flat_params = self.layout.pack(state)
@@ -202,6 +235,21 @@ class NnueTrainer:
         # (bucket-homogeneous MFMA tiles) instead of the FeatureTransformer forward's epilogue / backward rider
         self.fuse_l1 = (self.K == 1 and self.use_mfma and os.environ.get("NNUE_FUSE_L1", "1") != "0"
                         and lib.ftm_forward_l1_supported(B, self.F, self.P, self.L1, self.L2))
+        # Sharded update for bandwidth-sized flat buffers under collectives (SGD): reduce-scatter, per-shard clip + SGD with
+        # the norm assembled from all-gathered block partials, all-gather of the parameters.  NNUE_DP_SHARDED_UPDATE=0|1|auto
+        mode = os.environ.get("NNUE_DP_SHARDED_UPDATE", "auto")
+        self.sharded_update = (self.dp.collectives and optimizer == "sgd" and self.dp.buckets == 1 and mode != "0"
+                               and (mode == "1" or self.layout.count * 4 >= (64 << 20)))
+        if self.sharded_update:
+            per = self.layout.count // self.dp.world
+            self.grad_shard = torch.empty((per,), **f32)
+            self.norm_parts = 256
+            self.local_partials = torch.empty((self.norm_parts,), **f32)
+            self.all_partials = torch.empty((self.norm_parts * self.dp.world,), **f32)
+        # the collective(s) captured into the step graph (torch's NCCL path is capturable): one replay per step, no host
+        # round trip between the local kernels, the exchange and the update.  NNUE_DP_CAPTURE=0 keeps the eager collective.
+        self.capture_collectives = (self.dp.collectives and use_graph and self.dp.backend == "nccl" and self.dp.buckets == 1
+                                    and os.environ.get("NNUE_DP_CAPTURE", "1") != "0")
         self.steps_done = 0
         self.use_graph = use_graph
         self._g_local, self._g_update = {}, None
@@ -401,6 +449,23 @@ class NnueTrainer:
                 lib.ftm_backward_weight_update(self.d_ft, self.fm, self.p["input.weight"], mom, self.clip_coef, self.lr, self.momentum,
                                                self.weight_decay, scale, first)
 
+    def _exchange_and_update(self, first: bool, grad_scale: Optional[float] = None) -> None:
+        """Everything after the local kernels of a data-parallel step, as launches on the current stream: the gradient
+        exchange and the optimizer.  Capturable (no host synchronisation)."""
+        if not self.sharded_update:
+            self.dp.allreduce_sum(self.flat_grads, async_op=False)
+            self._update(first, grad_scale)
+            return
+        dp = self.dp
+        scale = dp.grad_scale if grad_scale is None else grad_scale
+        dp.reduce_scatter_sum(self.flat_grads, self.grad_shard)
+        lib.sqnorm_partials(self.grad_shard, self.local_partials)
+        dp.all_gather(self.all_partials, self.local_partials)  # rank-major, fixed order: every rank forms the identical norm
+        mom = dp.shard_of(self.flat_momentum) if self.flat_momentum is not None else None
+        lib.sgd_step(dp.shard_of(self.flat_params), self.grad_shard, mom, self.lr, self.momentum, self.weight_decay, self.max_grad_norm,
+                     scale, first, self.grad_norm, self.sgd_scratch, ext=(self.all_partials, 0, self.grad_shard.numel()))
+        dp.all_gather(self.flat_params, dp.shard_of(self.flat_params))
+
     def _optimizer_buffers(self):
         return [t for t in (self.flat_momentum, self.flat_exp_avg, self.flat_exp_avg_sq, self.adam_step_count) if t is not None]
 
@@ -486,8 +551,12 @@ class NnueTrainer:
 
     # ------------------------------------------------------------------ public
     def step(self, images: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None, slot: int = 0,
-             timers=None) -> torch.Tensor:
+             timers=None, global_count: Optional[int] = None) -> torch.Tensor:
         """One optimizer step on this rank's slice.  Returns the local mean loss (device scalar, no sync).
+
+        A short batch (fewer than the B images the trainer was built for; possibly none on some ranks) is padded; with
+        more than one rank pass ``global_count`` = the number of real samples over ALL ranks in this step (the loader knows
+        it), so that every rank scales the summed gradient by B / global_count -- the exact mean over the real samples.
 
         ``images``/``labels`` are copied into input slot ``slot`` first; pass None to train on what the slot
         already holds (zero-copy: fill ``trainer.inputs[slot]`` directly).  With ``timers`` ({C entry point:
@@ -497,7 +566,7 @@ class NnueTrainer:
         ragged = None
         if images is not None:
             if labels is None or images.shape[1:] != buf_images.shape[1:] or labels.shape[0] != images.shape[0] \
-                    or not 0 < images.shape[0] <= self.B:
+                    or not 0 <= images.shape[0] <= self.B or (images.shape[0] == 0 and self.dp.world == 1):
                 raise ValueError(f"trainer was built for images {tuple(buf_images.shape)} / labels ({self.B},)")
             n = images.shape[0]
             if n == self.B:
@@ -507,13 +576,15 @@ class NnueTrainer:
                 # short last batch of an epoch: pad with blank images whose label -1 the loss kernel ignores (zero
                 # loss, zero gradient row); the kernels divide by B, the exact mean over the n real samples is
                 # restored by scaling gradients and loss with B/n
-                if self.dp.world > 1:
-                    raise ValueError("ragged batches are only supported with a single rank")
-                ragged = self.B / n
+                if self.dp.world > 1 and global_count is None:
+                    raise ValueError("a short batch with more than one rank needs global_count (real samples over all ranks)")
+                ragged = self.B / n if self.dp.world == 1 else self.B * self.dp.world / int(global_count)
                 buf_images.zero_()
                 buf_images[:n].copy_(images, non_blocking=True)
                 buf_labels.fill_(-1)
                 buf_labels[:n].copy_(labels, non_blocking=True)
+        if ragged is None and global_count is not None and self.dp.world > 1 and int(global_count) != self.B * self.dp.world:
+            ragged = self.B * self.dp.world / int(global_count)  # this rank's slot is full but others are short: the same global mean
         _, upd_first, upd = self._plans(slot)
         first = self.steps_done == 0
         stream = torch.cuda.current_stream(self.dev).cuda_stream
@@ -536,6 +607,16 @@ class NnueTrainer:
             else:
                 self._run_local(slot, part, main, branch=False, timers=timers)
 
+        if graphs and self.capture_collectives and not first and ragged is None:
+            # data parallel, steady state: local kernels + exchange + update are ONE graph
+            if (slot, "full_dp") not in self._g_local:
+                def full_dp(st):
+                    self._run_local(slot, "all", st, branch=False)
+                    self._exchange_and_update(False)
+                self._g_local[(slot, "full_dp")] = self._capture(full_dp)
+            self._g_local[(slot, "full_dp")].replay()
+            self.steps_done += 1
+            return self.loss
         if graphs and not self.dp.collectives and not first and ragged is None:
             # single rank, steady state: local step + update are ONE graph (one replay per step)
             if (slot, "full") not in self._g_local:
@@ -548,6 +629,11 @@ class NnueTrainer:
             return self.loss
         if not self.dp.collectives:
             run("all")
+        elif self.sharded_update:
+            run("all")
+            self._exchange_and_update(first, grad_scale=self.dp.grad_scale * ragged if ragged is not None else None)
+            self.steps_done += 1
+            return self.loss * ragged if ragged is not None else self.loss
         elif not two_buckets:
             # one message: the whole flat gradient buffer, after the local graph; the wait is a stream dependency
             run("all")

@@ -82,6 +82,20 @@ def _worker(rank, port, out_dir):
             assert float((params[k] - single[k]).abs().max()) <= 2e-4 * scale, k
         with pytest.raises(ValueError):
             dp.shard(7)
+        # sharded update plumbing: reduce-scatter + all-gather of equal float4-aligned shards == all-reduce
+        lay2 = FlatLayout.of(model, pad_to=4 * WORLD)
+        assert lay2.count % (4 * WORLD) == 0 and lay2.count >= layout.count and lay2.offsets == layout.offsets
+        flat = torch.arange(lay2.count, dtype=torch.float32) * (rank + 1)
+        want = torch.arange(lay2.count, dtype=torch.float32) * 3  # ranks 1x + 2x
+        shard = torch.empty(lay2.count // WORLD)
+        dp.reduce_scatter_sum(flat.clone(), shard)
+        assert torch.equal(shard, dp.shard_of(want))
+        full = torch.zeros(lay2.count)
+        dp.shard_of(full).copy_(shard)
+        dp.all_gather(full, dp.shard_of(full))
+        assert torch.equal(full, want)
+        with pytest.raises(ValueError):
+            dp.shard_of(torch.zeros(lay2.count + 1))
         (Path(out_dir) / f"ok{rank}").write_text("ok")
     finally:
         dist.destroy_process_group()

@@ -1,6 +1,8 @@
-"""The overlapped data-parallel step of NnueTrainer with two ranks on ONE GPU (gloo backend moves the
-gradient buckets; on a multi-GPU node the same code runs over RCCL).  Checks: both ranks end with bitwise
-identical parameters, and the trajectory equals a single-process run on the global batch.  ``-m gpu``."""
+"""The data-parallel step of NnueTrainer.  Two ranks on ONE GPU (gloo moves the gradient; on a multi-GPU node the same
+code runs over RCCL): both ranks end with bitwise identical parameters and the trajectory equals a single-process run on
+the global batch -- for the one-message all-reduce, the two-bucket overlap, the sharded update (reduce-scatter / per-shard
+clip + SGD / all-gather) and a short last batch.  One rank over RCCL itself (backend "nccl", NNUE_DP_FORCE_COLLECTIVES):
+the collective captured inside the step's hipGraph.  Two ranks over RCCL when the box has two GPUs.  ``-m gpu``."""
 import os
 import socket
 import sys
@@ -14,7 +16,8 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 CFG = dict(grid=10, fps=8, l1=256, l2=32, l3=16, classes=10)
 OPT = dict(lr=0.01, momentum=0.9, weight_decay=2e-4, max_grad_norm=1.0)
-GLOBAL_BATCH, STEPS, WORLD = 32, 4, 2
+GLOBAL_BATCH, STEPS = 32, 4
+SHORT = 25  # real samples of the short last batch
 
 
 def _batch(step):
@@ -22,59 +25,106 @@ def _batch(step):
     return torch.randn(GLOBAL_BATCH, 3, 32, 32, generator=g), torch.randint(0, CFG["classes"], (GLOBAL_BATCH,), generator=g)
 
 
-def _build():
+def _build(device="cuda"):
     for p in (str(ROOT / "nnue-vision_amd"),):
         if p not in sys.path:
             sys.path.insert(0, p)
     import nnue
     torch.manual_seed(0)
-    return nnue.NNUE(nnue.GridFeatureSet(CFG["grid"], CFG["fps"]), CFG["l1"], CFG["l2"], CFG["l3"], num_classes=CFG["classes"]).to("cuda")
+    return nnue.NNUE(nnue.GridFeatureSet(CFG["grid"], CFG["fps"]), CFG["l1"], CFG["l2"], CFG["l3"], num_classes=CFG["classes"]).to(device)
 
 
-def _worker(rank, port, out_dir, use_graph, buckets):
+def _worker(rank, port, out_dir, world, backend, use_graph, env, short_last):
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", NNUE_DP_BUCKETS=str(buckets))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", **env)
+    dev = rank if backend == "nccl" and torch.cuda.device_count() >= world else 0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        model = _build()
+        model = _build(torch.device("cuda", dev))
         from nnue_hip.trainer import NnueTrainer
-        tr = NnueTrainer(model, GLOBAL_BATCH // WORLD, (32, 32), use_graph=use_graph, input_slots=2, **OPT)
-        assert tr.dp.world == WORLD and tr.bucket_split == 8 + 8 * 27 and tr.dp.buckets == buckets
+        per = GLOBAL_BATCH // world
+        tr = NnueTrainer(model, per, (32, 32), use_graph=use_graph, input_slots=2, **OPT)
+        assert tr.dp.world == world and tr.bucket_split == 8 + 8 * 27
+        assert tr.sharded_update == (env.get("NNUE_DP_SHARDED_UPDATE") == "1")
+        assert tr.capture_collectives == (backend == "nccl" and use_graph and env.get("NNUE_DP_CAPTURE", "1") != "0")
         sl = tr.dp.shard(GLOBAL_BATCH)
         losses = []
         for s in range(STEPS):
             images, labels = _batch(s)
-            losses.append(float(tr.step(images[sl].cuda(), labels[sl].cuda(), slot=s % 2)))
+            if short_last and s == STEPS - 1:  # the global batch holds SHORT real samples; the last rank(s) come up short
+                lo, hi = min(sl.start, SHORT), min(sl.stop, SHORT)
+                losses.append(float(tr.step(images[lo:hi].to(tr.dev), labels[lo:hi].to(tr.dev), slot=s % 2, global_count=SHORT)))
+            else:
+                losses.append(float(tr.step(images[sl].to(tr.dev), labels[sl].to(tr.dev), slot=s % 2)))
         torch.cuda.synchronize()
         torch.save({"flat": tr.flat_params.cpu(), "norm": float(tr.grad_norm), "losses": losses}, Path(out_dir) / f"rank{rank}.pt")
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("buckets", (1, 2))
-@pytest.mark.parametrize("use_graph", (False, True))
-def test_two_ranks_match_single_process(tmp_path, use_graph, buckets):
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    mp.spawn(_worker, args=(port, str(tmp_path), use_graph, buckets), nprocs=WORLD, join=True)
-    r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
-    r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
-    assert torch.equal(r0["flat"], r1["flat"]), "replicas diverged"
-    assert r0["norm"] == r1["norm"]
-    # single process, whole batch
+def _reference(use_graph, short_last):
     model = _build()
     from nnue_hip.trainer import NnueTrainer
     tr = NnueTrainer(model, GLOBAL_BATCH, (32, 32), use_graph=use_graph, **OPT)
-    ref_losses = []
+    losses = []
     for s in range(STEPS):
         images, labels = _batch(s)
-        ref_losses.append(float(tr.step(images.cuda(), labels.cuda())))
-    ref = tr.flat_params.cpu()
+        n = SHORT if (short_last and s == STEPS - 1) else GLOBAL_BATCH
+        losses.append(float(tr.step(images[:n].cuda(), labels[:n].cuda())))
+    return tr.flat_params.cpu(), float(tr.grad_norm), losses, tr.layout.count
+
+
+def _run(tmp_path, world, backend, use_graph, env, short_last=False):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(port, str(tmp_path), world, backend, use_graph, env, short_last), nprocs=world, join=True)
+    ranks = [torch.load(tmp_path / f"rank{r}.pt", weights_only=True) for r in range(world)]
+    for r in ranks[1:]:
+        assert torch.equal(ranks[0]["flat"], r["flat"]), "replicas diverged"
+        assert ranks[0]["norm"] == r["norm"]
+    ref, ref_norm, ref_losses, count = _reference(use_graph, short_last)
+    got = ranks[0]["flat"][:count]  # the flat buffers are padded to a multiple of 4 * world
     scale = float(ref.abs().max())
-    assert float((r0["flat"] - ref).abs().max()) <= 2e-4 * scale
-    assert abs(r0["norm"] - float(tr.grad_norm)) <= 2e-4 * float(tr.grad_norm)
-    # the two half-batch mean losses average to the whole-batch loss
-    for a, b, c in zip(r0["losses"], r1["losses"], ref_losses):
-        assert abs((a + b) / 2 - c) <= 2e-4 * max(1.0, abs(c))
+    assert float((got - ref[:got.numel()]).abs().max()) <= 2e-4 * scale
+    assert abs(ranks[0]["norm"] - ref_norm) <= 2e-4 * ref_norm
+    # per-rank mean losses average to the whole-batch loss
+    for s in range(STEPS):
+        mean = sum(r["losses"][s] for r in ranks) / world
+        assert abs(mean - ref_losses[s]) <= 2e-4 * max(1.0, abs(ref_losses[s])), (s, mean, ref_losses[s])
+
+
+@pytest.mark.parametrize("buckets", (1, 2))
+@pytest.mark.parametrize("use_graph", (False, True))
+def test_two_ranks_match_single_process(tmp_path, use_graph, buckets):
+    _run(tmp_path, 2, "gloo", use_graph, {"NNUE_DP_BUCKETS": str(buckets)})
+
+
+@pytest.mark.parametrize("use_graph", (False, True))
+def test_two_ranks_with_the_sharded_update(tmp_path, use_graph):
+    """reduce-scatter, per-shard clip + SGD with the norm assembled from all-gathered partials, all-gather."""
+    _run(tmp_path, 2, "gloo", use_graph, {"NNUE_DP_SHARDED_UPDATE": "1"})
+
+
+@pytest.mark.parametrize("sharded", ("0", "1"))
+def test_two_ranks_with_a_short_last_batch(tmp_path, sharded):
+    """25 real samples in a global batch of 32: rank 0 holds 16, rank 1 nine; the mean is over the 25."""
+    _run(tmp_path, 2, "gloo", True, {"NNUE_DP_SHARDED_UPDATE": sharded}, short_last=True)
+
+
+@pytest.mark.parametrize("env", ({}, {"NNUE_DP_SHARDED_UPDATE": "1"}, {"NNUE_DP_CAPTURE": "0"}))
+def test_one_rank_over_rccl_with_the_collective_inside_the_graph(tmp_path, env):
+    """backend "nccl" (= RCCL) with a single rank, collectives forced on: the all-reduce (or reduce-scatter / all-gather
+    pair) is captured into the step's hipGraph and replayed; the trajectory is the plain single-rank one."""
+    _run(tmp_path, 1, "nccl", True, {"NNUE_DP_FORCE_COLLECTIVES": "1", **env})
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI between ranks)")
+@pytest.mark.parametrize("env", ({}, {"NNUE_DP_SHARDED_UPDATE": "1"}, {"NNUE_DP_CAPTURE": "0"}))
+def test_two_ranks_over_rccl(tmp_path, env):
+    _run(tmp_path, 2, "nccl", True, env)
+    _run(tmp_path, 2, "nccl", True, env, short_last=True)
