@@ -45,6 +45,7 @@ WORKLOADS = {
 OPT = dict(lr=0.01, momentum=0.9, weight_decay=2e-4, max_grad_norm=1.0)  # config/train_nnue.py:29-36
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA, dense (= the f32 vector rate)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1-sparsity headline)
 
 
 def parse():
@@ -126,7 +127,7 @@ def cpu_baseline(cfg, budget_s):
     (forward, backward, clip, SGD) on the same synthetic shapes; bounded by `budget_s`."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import nnue_oracle as orc
-    cores = min(os.cpu_count() or 1, 16)  # the box's CPU share for one GPU
+    cores = min(os.cpu_count() or 1, 16)  # capped at 16: the box's CPU share for one GPU ("of" = what the host reports)
     torch.set_num_threads(cores)
     stride = orc.conv_stride(cfg["image"], cfg["grid"])
     params = orc.init_params(cfg["grid"], cfg["fps"], cfg["l1"], cfg["l2"], cfg["l3"], cfg["classes"], 0, buckets=cfg.get("buckets", 1))
@@ -148,7 +149,7 @@ def cpu_baseline(cfg, budget_s):
     for _ in range(steps):
         one()
     dt = time.perf_counter() - t0
-    return {"value": round(batch * steps / dt, 1), "unit": "images/sec", "cores": cores, "kind": "port",
+    return {"value": round(batch * steps / dt, 1), "unit": "images/sec", "cores": cores, "of": os.cpu_count(), "kind": "port",
             "sample": f"{steps} full training steps of batch {batch} after 1 warm-up ({dt:.1f} s), "
                       f"oracle loop form (per-sample Python loops + autograd, as nnue.py:601-633/:694-708), torch CPU fp32"}
 
@@ -289,6 +290,24 @@ def main():
                f"{ftp}_backward_weight_update": n_mean * row * B}
     kernels = {k: {"avg_us": round(dur_us[k], 2), **({"alg_GBps": round(alg[k] / dur_us[k] * 1e-3, 1)} if k in alg and dur_us[k] > 0 else {})}
                for k in names}
+    KERNEL_OF = {  # C entry point -> (kernel name prefix, substring) in rocprof / PMC summaries
+        "nnue_ftm_forward": ("ftm_gemm", "FwdEpi"), "nnue_ftm_forward_l1": ("ftm_forward_l1", ""),
+        "nnue_ftm_backward": ("ftm_backward", ""), "nnue_ftm_backward_bucketed": ("ftm_backward", ""),
+        "nnue_ftm_backward_weight": ("ftm_gemm", "BwwEpi"), "nnue_ftm_backward_values": ("ftm_gemm", "ValEpi"),
+        "nnue_ftm_backward_weight_update": ("ftm_gemm", "BwwSgdEpi"),
+        "nnue_ftb_forward": ("ftb_gather_kernel", ", 0,"), "nnue_ftb_backward_weight": ("ftb_gather_kernel", ", 1,"),
+        "nnue_ftb_backward_values": ("ftb_values_kernel", ""), "nnue_ft_forward": ("ft_forward_wide", ""),
+        "nnue_ft_backward_weight": ("ft_backward_weight_wide", ""), "nnue_ft_backward_values": ("ft_backward_values_wide", "")}
+
+    def match_kernel(entry, name):
+        want = KERNEL_OF.get(entry)
+        if not want:
+            return False
+        name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+        if want[1] == "BwwEpi" and "BwwSgdEpi" in name:
+            return False
+        return name.startswith(want[0]) and want[1] in name
+
     def pmc_traffic(entry):
         """HBM-side bytes per launch of the kernel behind a C entry point, from the committed rocprofv3 --pmc passes
         (profiles/*pmc_traffic.json, FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; separate passes per
@@ -297,46 +316,80 @@ def main():
         if not files:
             return None
         data = json.loads(files[-1].read_text())
-        kernels = data.get("workloads", {}).get(args.workload) or (data.get("kernels") if args.workload == "c2" else None)
+        kernels = data.get("workloads", {}).get(args.workload.replace("c3k1", "c3")) or (data.get("kernels") if args.workload == "c2" else None)
         if not kernels:
             return None
-        want = {"nnue_ftm_forward": ("ftm_gemm_kernel", "FwdEpi"), "nnue_ftm_forward_l1": ("ftm_forward_l1_kernel", ""), "nnue_ftm_backward": ("ftm_backward_kernel", ""), "nnue_ftm_backward_bucketed": ("ftm_backward_kernel", ""), "nnue_ftm_backward_weight": ("ftm_gemm_kernel", "BwwEpi"),
-                "nnue_ftm_backward_values": ("ftm_gemm_kernel", "ValEpi"),
-                "nnue_ftb_forward": ("ftb_gather_kernel", ", 0,"), "nnue_ftb_backward_weight": ("ftb_gather_kernel", ", 1,"),
-                "nnue_ftb_backward_values": ("ftb_values_kernel", ""), "nnue_ft_forward": ("ft_forward_wide", ""),
-                "nnue_ft_backward_weight": ("ft_backward_weight_wide", ""), "nnue_ft_backward_values": ("ft_backward_values_wide", "")}.get(entry)
         for name, v in kernels.items():
-            if want and name.startswith(want[0]) and want[1] in name:
-                return {"bytes": v["hbm_bytes_corrected"], "l2_hit_rate": v["l2_hit_rate"], "source": f"profiles/{files[-1].name}"}
-        if entry == "nnue_ftm_backward":  # two launches at this shape: weight-gradient + value-gradient kernels
-            parts = [v for name, v in kernels.items() if name.startswith("ftm_gemm_kernel") and ("BwwEpi" in name or "ValEpi" in name)]
-            if len(parts) == 2:
-                return {"bytes": sum(v["hbm_bytes_corrected"] for v in parts), "l2_hit_rate": None,
-                        "source": f"profiles/{files[-1].name} (sum of the two launches)"}
+            if match_kernel(entry, name):
+                return {"bytes": v["hbm_bytes_corrected"], "l2_hit_rate": v["l2_hit_rate"], "kernel": name,
+                        "source": f"profiles/{files[-1].name} (committed counter passes of the eager step; not collected in this run)"}
+        return None
+
+    def rocprof_avg_us(entry):
+        """Average duration of that kernel in the latest committed `rocprofv3 --kernel-trace --stats` summary of this
+        workload's bench command (profiles/*kernel_stats_<workload>.csv)."""
+        files = sorted((ROOT / "profiles").glob(f"*kernel_stats_{args.workload.replace('c3k1', 'c3')}.csv"))
+        if not files:
+            return None
+        import csv
+        with open(files[-1]) as fh:
+            for rec in csv.DictReader(fh):
+                if match_kernel(entry, rec["Name"]) and int(rec["Calls"]) >= 10:
+                    return {"us": round(float(rec["AverageNs"]) / 1e3, 2), "source": f"profiles/{files[-1].name}"}
         return None
 
     dom = max(alg, key=lambda k: dur_us[k])
     table_mb = model.input.weight.numel() * 4 / 1e6
     alg_rate = alg[dom] / (dur_us[dom] * 1e-6) / 1e9 if dur_us[dom] > 0 else 0.0
     if trainer.ft_path == "mfma":
-        # dense f32-MFMA products: priced in flops of the product actually executed (2 M N K, all positions, not only
-        # the active ones) against the f32 matrix peak; the SURVEY 8d algorithmic-byte rate is kept beside it
+        # Products over the whole map (active and inactive positions).  Each product is priced on the unit it runs on
+        # (nnue_ftm_uses_bf16): the f32-input MFMA (157.3 TF) or, for the two products whose A operand is the binary map,
+        # three bf16 MFMAs per logical product (2.5 PF dense; 3x the flops as matrix work).  Beside it the compulsory HBM
+        # bytes of the launch; the bound reported is whichever ideal time is longer.
+        from nnue_hip import lib as _lib
         direct = min(trainer.F - 1, trainer.P)
-        flops = {f"{ftp}_forward": 2.0 * B * direct * cfg["l1"], f"{ftp}_backward_weight": 2.0 * B * direct * cfg["l1"],
-                 f"{ftp}_backward_values": 2.0 * B * trainer.P * cfg["l1"]}
-        flops[f"{ftp}_backward"] = flops[f"{ftp}_backward_weight"] + flops[f"{ftp}_backward_values"]
-        if getattr(trainer, "ride_dw1", False):  # + the classifier's first-layer weight gradient riding in the launch
-            flops[f"{ftp}_backward"] += 2.0 * B * cfg["l1"] * cfg["l2"]
-        flops[f"{ftp}_backward_bucketed"] = flops[f"{ftp}_backward"]
-        flops[f"{ftp}_backward_weight_update"] = flops[f"{ftp}_backward_weight"]
-        flops[f"{ftp}_forward_l1"] = flops[f"{ftp}_forward"] + 2.0 * B * cfg["l1"] * cfg["l2"]  # + the layer-1 product
-        achieved = flops[dom] / (dur_us[dom] * 1e-6) / 1e12 if dur_us[dom] > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": (pmc_traffic(dom) or {}).get("bytes"),
-                    "traffic_detail": pmc_traffic(dom), "flops_per_launch": int(flops[dom]), "avg_launch_us": round(dur_us[dom], 2),
-                    "alg_bytes_per_launch": int(alg[dom]), "alg_GBps": round(alg_rate, 1),
-                    "regime": "v_mfma_f32_16x16x4_f32 products over the whole map (active and inactive positions); "
-                              "table %.1f MB" % table_mb}
+        L1, L2, F, P = cfg["l1"], cfg["l2"], trainer.F, trainer.P
+        uses = lambda which: bool(_lib.load().nnue_ftm_uses_bf16(which, B, F, P, L1))  # noqa: E731
+        f_fwd, f_w, f_v, f_l1 = 2.0 * B * direct * L1, 2.0 * B * direct * L1, 2.0 * B * P * L1, 2.0 * B * L1 * L2
+        tbl, mp, act = direct * L1 * 4.0, float(B * P), B * L1 * 4.0
+        work = {  # entry -> ([(unit, useful flops)], compulsory bytes)
+            f"{ftp}_forward": ([("bf16" if uses(0) else "f32", f_fwd)], tbl + mp + act),
+            f"{ftp}_forward_l1": ([("bf16" if uses(0) else "f32", f_fwd), ("f32", f_l1)], tbl + mp + act + (L1 // 64) * B * L2 * 4.0),
+            f"{ftp}_backward_weight": ([("bf16" if uses(1) else "f32", f_w)], mp + act + tbl),
+            f"{ftp}_backward_values": ([("f32", f_v)], act + F * L1 * 4.0 + mp + B * P * 4.0),
+            f"{ftp}_backward_weight_update": ([("bf16", f_w)], mp + act + 2 * tbl + (2 * tbl if OPT["momentum"] else 0)),
+        }
+        bw = [("bf16" if uses(2) else "f32", f_w), ("f32", f_v)] + ([("f32", f_l1)] if getattr(trainer, "ride_dw1", False) else [])
+        work[f"{ftp}_backward"] = (bw, 2 * mp + act + F * L1 * 4.0 + tbl + B * P * 4.0)
+        work[f"{ftp}_backward_bucketed"] = work[f"{ftp}_backward"]
+        PEAK = {"f32": MFMA_F32_PEAK_TFLOPS, "bf16": MFMA_BF16_PEAK_TFLOPS}
+        units, comp_bytes = work[dom]
+        useful = sum(f for _, f in units)
+        t_mfma = sum(f * (3.0 if u == "bf16" else 1.0) / (PEAK[u] * 1e12) for u, f in units)  # seconds at the units' peaks
+        t_hbm = comp_bytes / (HBM_PEAK_GBS * 1e9)
+        dur = dur_us[dom] * 1e-6
+        rp = rocprof_avg_us(dom)
+        common = {"kernel": dom, "traffic": (pmc_traffic(dom) or {}).get("bytes"), "traffic_detail": pmc_traffic(dom),
+                  "compulsory_bytes": int(comp_bytes), "flops_per_launch": int(useful),
+                  "matrix_work": [{"unit": u, "useful_flops": int(f), "peak_TFLOPs": PEAK[u], "mfma_flops": int(f * (3 if u == "bf16" else 1))}
+                                  for u, f in units],
+                  "ideal_us": {"mfma": round(t_mfma * 1e6, 2), "hbm": round(t_hbm * 1e6, 2)},
+                  "avg_launch_us": round(dur_us[dom], 2), "rocprof_avg_us": rp["us"] if rp else None, "rocprof_source": rp["source"] if rp else None,
+                  "alg_bytes_per_launch": int(alg[dom]), "alg_GBps": round(alg_rate, 1)}
+        if t_hbm >= t_mfma:
+            rate = comp_bytes / dur / 1e9 if dur > 0 else 0.0
+            roofline = {"bound": "hbm", "achieved": round(rate, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(rate / HBM_PEAK_GBS, 4), **common,
+                        "regime": "compulsory bytes of the launch (table %.1f MB streamed once, parameters and momentum read and written where the "
+                                  "update is fused) / HIP-event duration; the matrix work of the launch would take %.1f us at its units' peaks"
+                                  % (table_mb, t_mfma * 1e6)}
+        else:
+            blended = useful / t_mfma / 1e12  # the peak this launch could reach given which unit each product runs on
+            achieved = useful / dur / 1e12 if dur > 0 else 0.0
+            roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(blended, 1), "unit": "TFLOP/s",
+                        "frac": round(achieved / blended, 4), **common,
+                        "regime": "useful flops of the products in the launch (2 M N K over the whole map) / HIP-event duration, against the "
+                                  "peak of the unit each product runs on (f32-input MFMA 157.3 TF; bf16 MFMA 2.5 PF at three MFMAs per "
+                                  "product for the exact split); table %.1f MB" % table_mb}
     else:
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(alg_rate, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(alg_rate / HBM_PEAK_GBS, 4), "traffic": (pmc_traffic(dom) or {}).get("bytes"),

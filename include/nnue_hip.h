@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 22
+#define NNUE_HIP_ABI_VERSION 23
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -406,6 +406,11 @@ int nnue_ftm_backward_weight_update(const uint8_t* bits, const float* d_out, int
                                     float* weight, float* momentum_rows, const float* coef,
                                     float lr, float momentum, float weight_decay, float grad_scale,
                                     int first_step, nnue_stream_t stream);
+
+/* Reporting only: 1 when the product of this shape runs on the bf16 matrix unit (exact three-way split of the f32
+ * operand), 0 on the f32 MFMA.  which: 0 forward, 1 stand-alone weight gradient, 2 weight-gradient tiles of the merged
+ * backward launch, 3 weight gradient with the update in its epilogue. */
+int nnue_ftm_uses_bf16(int which, int B, int F, int P, int L1);
 
 /* nnue_ftm_backward for bucketed layer stacks (declared with the FeatureTransformer entry points above): d_w1 [K][L2][L1],
  * ft_grouped / d_z1_grouped in grouped row order (grouped_rows = 16 * nnue_bucket_tile_count rows, padding rows zero),

@@ -1535,3 +1535,16 @@ extern "C" int nnue_ftm_backward_weight_update(const uint8_t* bits, const float*
                        direct, L1, B);
   return nnue_launch_status("nnue_ftm_backward_weight_update");
 }
+
+// Which matrix unit a product of this shape runs on (the launch policy above, for reporting: bench.py prices a kernel
+// against the peak of the unit it used).  which: 0 forward, 1 stand-alone weight gradient, 2 weight-gradient tiles of the
+// merged backward launch, 3 weight gradient with the update in its epilogue.  1 = bf16-split tiles, 0 = f32 MFMA.
+extern "C" int nnue_ftm_uses_bf16(int which, int B, int F, int P, int L1) {
+  if (!nnue_ftm_supported(F, P, L1) || !shape_ok(B, F, P, L1)) return 0;
+  const int direct = (F - 1 < P) ? F - 1 : P;
+  if (direct <= 0) return 0;
+  if (which == 0) return plan(B, L1, direct, true, true, true).cfg >= 6;
+  if (which == 1) return plan(direct, L1, B, false, false, true).cfg >= 6;
+  if (which == 2) { bool big = false; return merged_backward_shape(B, F, P, L1, &big) ? merged_bf_wm() != 0 : plan(direct, L1, B, false, false, true).cfg >= 6; }
+  return 1;
+}

@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -113,6 +113,7 @@ SIGNATURES = {
                                 _c_p, _c_p, _c_i64, _c_p]),
     "nnue_sgd_step": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_int,
                                _c_p, _c_p, _c_i64, _c_p, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_i64, _c_i64, _c_p, _c_int, _c_p]),
+    "nnue_ftm_uses_bf16": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int]),
     "nnue_sqnorm_partials": (_c_int, [_c_p, _c_i64, _c_p, _c_int, _c_p]),
     "nnue_ftm_gram_sq_count": (_c_i64, [_c_int, _c_int]),
     "nnue_ftm_gram_sqnorm": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),

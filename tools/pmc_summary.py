@@ -25,7 +25,7 @@ def main():
     f, w, t = per_kernel(fetch), per_kernel(write), per_kernel(tcc)
     out = {}
     for k in sorted(f):
-        if not k.startswith(("ftm_", "ftb_", "ft_")):
+        if not k.startswith(("ftm_", "ftb_", "ft_", "gram_", "sgd_apply", "l1_", "tail_train", "conv_binarize", "ste_conv")):
             continue
         fs, ws = f[k].get("FETCH_SIZE", 0.0), w.get(k, {}).get("WRITE_SIZE", 0.0)
         hit, miss = t.get(k, {}).get("TCC_HIT_sum", 0.0), t.get(k, {}).get("TCC_MISS_sum", 0.0)
@@ -33,8 +33,8 @@ def main():
                   "TCC_HIT_sum": int(hit), "TCC_MISS_sum": int(miss), "l2_hit_rate": round(hit / (hit + miss), 4) if hit + miss else None}
     base.setdefault("workloads", {})[workload] = out
     base["_about"] = ("rocprofv3 --pmc passes (one counter group per run: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum; no trace "
-                      "domains) of the eager probes tools/probe_fwd_l1.py (c2: fused forward + merged backward with the d_w1 tiles) and "
-                      "tools/probe_ftm.py (c4, carried over from r01n). FETCH_SIZE/WRITE_SIZE in KiB as reported; per MI355X_MICROARCH.md "
+                      "domains) of the shipped training step launched eagerly (tools/probe_step.py <workload>, the kernels the bench "
+                      "line's graph replays). FETCH_SIZE/WRITE_SIZE in KiB as reported; per MI355X_MICROARCH.md "
                       "(HBM section) FETCH_SIZE under-counts wide coalesced reads by 2x on gfx950: hbm_bytes_corrected = (2*FETCH + "
                       "WRITE)*1024. Averages over the launches of the run; summarised by tools/pmc_summary.py.")
     json.dump(base, sys.stdout, indent=1)
