@@ -588,17 +588,34 @@ __device__ __forceinline__ void gemm_tile_bf(unsigned char* __restrict__ smem, c
     else return n_abs;
   };
   // ---- staging coordinates
-  // f32 operand: thread = (k block of 8, n block of 4); lanes walk n first (coalesced 16-byte loads along a row)
-  const int bn4 = (tid & 15) * 4, bk8 = (tid >> 4) * 8;
+  // f32 operand: thread = (k block of 8, n block of 4).  Inside a 16-lane group the lanes take 4 n blocks x 4 k blocks, so
+  // that their 16-byte LDS stores (row n, chunk k/8, chunk XOR-swizzled by the row) fall into 16 different 16-byte slots:
+  // with 16 n blocks x 1 k block per group the rows 4 j + e repeat modulo 16 and the stores were 4-way bank-conflicted.
+  // A wave still reads 256 contiguous bytes of each of its k rows.
+  const int bn4 = (((lane & 3) | ((lane >> 4) << 2))) * 4, bk8 = (((lane >> 2) & 3) | (wave << 2)) * 8;
   const int b_off = b_col(n_base + bn4) * 4;  // byte offset inside a row
   // A, forward (bytes contiguous along k): 16-byte groups, (row, 16 k); BM * 8 groups
   // A, weight gradient (bytes contiguous along m): thread = (k block of 8, m block of 4); BM / 4 x 16 blocks
+  // (same 4 x 4 arrangement inside a 16-lane group as for the f32 operand: block index -> (m block, k block))
+  auto a_block = [&](int g) {
+    constexpr int MB = BM / 4;  // m blocks per k block
+    const int grp = g >> 4, l = g & 15;  // 16 consecutive blocks = 4 m blocks x 4 k blocks
+    const int groups_m = MB / 4;         // groups along m per 4 k blocks
+    const int gm = grp % groups_m, gk = grp / groups_m;
+    return ((gk * 4 + (l >> 2)) * MB) + gm * 4 + (l & 3);
+  };
   constexpr int AGK = BM * 8 / 256;                 // forward: 16-byte loads per thread
   constexpr int AGR = (BM / 4) * 16 / 256 ? (BM / 4) * 16 / 256 : 1;  // weight gradient: 8 x 4 blocks per thread (BM = 32: half the threads)
-  u32x4 ra[AKC ? AGK : 1];
-  unsigned rat[AKC ? 1 : AGR][8];
-  u32x4 rb[8];
-  auto fetch = [&](int k0) {
+  // two register sets: the loads of K tile t+2 are issued while tile t is contracted -- with the bf16 unit a tile's MFMA
+  // phase is too short to cover one L2 round trip, so one tile of look-ahead left the loop latency-bound
+  struct Regs {
+    u32x4 ra[AKC ? AGK : 1];
+    unsigned rat[AKC ? 1 : AGR][8];
+    u32x4 rb[8];
+  };
+  Regs set0, set1;
+  auto fetch = [&](int k0, Regs& R) {
+    auto& ra = R.ra; auto& rat = R.rat; auto& rb = R.rb;
     if constexpr (AKC) {
 #pragma unroll
       for (int i = 0; i < AGK; ++i) {
@@ -608,7 +625,7 @@ __device__ __forceinline__ void gemm_tile_bf(unsigned char* __restrict__ smem, c
     } else {
 #pragma unroll
       for (int i = 0; i < AGR; ++i) {
-        const int g = tid + 256 * i;
+        const int g = a_block(tid + 256 * i);
         const int m4 = (g % (BM / 4)) * 4, k8 = (g / (BM / 4)) * 8;
         const bool on = g < (BM / 4) * 16;
 #pragma unroll
@@ -619,7 +636,8 @@ __device__ __forceinline__ void gemm_tile_bf(unsigned char* __restrict__ smem, c
 #pragma unroll
     for (int j = 0; j < 8; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsb, (k0 + bk8 + j) * mb.ld * 4 + b_off, 0, 0);
   };
-  auto stage = [&]() {
+  auto stage = [&](const Regs& R) {
+    const auto& ra = R.ra; const auto& rat = R.rat; const auto& rb = R.rb;
     if constexpr (AKC) {
 #pragma unroll
       for (int i = 0; i < AGK; ++i) {
@@ -636,7 +654,7 @@ __device__ __forceinline__ void gemm_tile_bf(unsigned char* __restrict__ smem, c
     } else {
 #pragma unroll
       for (int i = 0; i < AGR; ++i) {
-        const int g = tid + 256 * i;
+        const int g = a_block(tid + 256 * i);
         if (g < (BM / 4) * 16) {
           const int m4 = (g % (BM / 4)) * 4, c = g / (BM / 4);
 #pragma unroll
@@ -688,11 +706,7 @@ __device__ __forceinline__ void gemm_tile_bf(unsigned char* __restrict__ smem, c
 
   FusedL1Pre<Epi::kFusedL1 ? BM : 32> l1pre;
   if constexpr (Epi::kFusedL1) fused_l1_prefetch<BM>(epi, l1pre, m_base, tile_n, m0, n0, r, q, wave);
-  fetch(k_lo);
-  for (int k0 = k_lo; k0 < k_hi; k0 += kBfK) {
-    stage();
-    __syncthreads();
-    if (k0 + kBfK < k_hi) fetch(k0 + kBfK);
+  auto contract = [&]() {
 #pragma unroll
     for (int kb = 0; kb < kBfK / 32; ++kb) {
       const int c = kb * 4 + q;  // this lane's 8 k of the 32-k block
@@ -711,6 +725,22 @@ __device__ __forceinline__ void gemm_tile_bf(unsigned char* __restrict__ smem, c
 #pragma unroll
           for (int t = 0; t < TN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[pnum][t], acc[i][t], 0, 0, 0);
     }
+  };
+  // fetches past k_hi are issued unconditionally: the buffer range check returns zeros and a conditional prefetch would
+  // make the compiler's wait-count merge assume the shorter queue
+  fetch(k_lo, set0);
+  fetch(k_lo + kBfK, set1);
+  for (int k0 = k_lo; k0 < k_hi; k0 += 2 * kBfK) {
+    stage(set0);
+    __syncthreads();
+    fetch(k0 + 2 * kBfK, set0);
+    contract();
+    __syncthreads();
+    if (k0 + kBfK >= k_hi) break;
+    stage(set1);
+    __syncthreads();
+    fetch(k0 + 3 * kBfK, set1);
+    contract();
     __syncthreads();
   }
   if constexpr (Epi::kFusedL1) {
