@@ -606,14 +606,12 @@ __device__ __forceinline__ void gemm_tile_bf(unsigned char* __restrict__ smem, c
   };
   constexpr int AGK = BM * 8 / 256;                 // forward: 16-byte loads per thread
   constexpr int AGR = (BM / 4) * 16 / 256 ? (BM / 4) * 16 / 256 : 1;  // weight gradient: 8 x 4 blocks per thread (BM = 32: half the threads)
-  // two register sets: the loads of K tile t+2 are issued while tile t is contracted -- with the bf16 unit a tile's MFMA
-  // phase is too short to cover one L2 round trip, so one tile of look-ahead left the loop latency-bound
   struct Regs {
     u32x4 ra[AKC ? AGK : 1];
     unsigned rat[AKC ? 1 : AGR][8];
     u32x4 rb[8];
   };
-  Regs set0, set1;
+  Regs set0;
   auto fetch = [&](int k0, Regs& R) {
     auto& ra = R.ra; auto& rat = R.rat; auto& rb = R.rb;
     if constexpr (AKC) {
@@ -726,20 +724,13 @@ __device__ __forceinline__ void gemm_tile_bf(unsigned char* __restrict__ smem, c
           for (int t = 0; t < TN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[pnum][t], acc[i][t], 0, 0, 0);
     }
   };
-  // fetches past k_hi are issued unconditionally: the buffer range check returns zeros and a conditional prefetch would
-  // make the compiler's wait-count merge assume the shorter queue
+  // (two register sets with the loads of tile t+2 in flight were measured and lose: 83 -> 108 us for the 224x224 forward,
+  // 109 -> 193 us for its weight gradient, whose K = batch is a single tile; nothing at the CIFAR shapes)
   fetch(k_lo, set0);
-  fetch(k_lo + kBfK, set1);
-  for (int k0 = k_lo; k0 < k_hi; k0 += 2 * kBfK) {
+  for (int k0 = k_lo; k0 < k_hi; k0 += kBfK) {
     stage(set0);
     __syncthreads();
-    fetch(k0 + 2 * kBfK, set0);
-    contract();
-    __syncthreads();
-    if (k0 + kBfK >= k_hi) break;
-    stage(set1);
-    __syncthreads();
-    fetch(k0 + 3 * kBfK, set1);
+    if (k0 + kBfK < k_hi) fetch(k0 + kBfK, set0);
     contract();
     __syncthreads();
   }
