@@ -1157,7 +1157,9 @@ Shape plan(int M, int N, int K, bool prefer_m, bool allow_split, bool bf_ok = fa
     // with 32-row bf16 tiles, 25.7 with 64-row ones that leave half the CUs idle, 20.3 with the f32 kernel).
     for (int c = 8; c >= 7; --c)
       if (tiles(c) >= 256) { cfg = c; break; }
-    if (small_m) cfg = 8;
+    // split-K forward of a small batch: only where K still gives the 128-deep bf16 tiles many slabs (the 65 536-row table);
+    // at K = 799 the f32 tiles (K tile 32: six slabs) fill more of the chip than one workgroup walking seven bf16 K tiles
+    if (small_m) cfg = (K >= 4096) ? 8 : 2;
     if (force_bf_bm == 32 || force_bf_bm == 64 || force_bf_bm == 128) cfg = force_bf_bm == 32 ? 6 : force_bf_bm == 64 ? 7 : 8;
   }
   Shape s;
