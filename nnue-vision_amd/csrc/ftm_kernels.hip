@@ -362,6 +362,8 @@ struct is_rmw<Epi, decltype((void)Epi::kRmw)> { static constexpr bool value = Ep
 // lane group and row -- 64-byte pieces, a poor shape for a read-modify-write of two 268 MB arrays -- so the tile goes
 // through LDS and every thread then owns whole float4 runs of a row: all of the tile's parameter and momentum loads are
 // issued before the first result is combined (64 KB in flight per workgroup at 128 x 64).
+// (Requesting the tile's parameters and momentum before the K loop instead -- 64 more live registers -- was measured and
+// loses: 234 vs 200 us at the 224x224 shape; two workgroups per CU already overlap one's epilogue with the other's product.)
 template <int BM, int BN, class Epi>
 __device__ __forceinline__ void rmw_tile(float* __restrict__ smem, const Epi& epi, const f32x4 (&acc)[BM / 32][BN / 32], int M, int N,
                                          int m_base, int n_base, int m0, int n0) {
@@ -1321,6 +1323,10 @@ extern "C" int nnue_ftm_backward_values(const uint8_t* bits, const float* d_out,
   NNUE_REQUIRE(nnue_aligned16(d_out) && nnue_aligned16(weight), NNUE_E_ARG, "nnue_ftm_backward_values: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const Shape s = plan(B, P, L1, true, false);
+  // Stays on the f32 MFMA: both operands are f32, so the bf16 unit needs both splits and six plane products per pair
+  // (hh, hm, mh, hl, lh, mm).  Built and measured in round 2 with the truncation split (4.5 VALU per value), 128 x 64 x 128
+  // tiles, six LDS images (144 KB, one workgroup per CU): 178 us against 153 us for this kernel at the 224x224 shape --
+  // with one workgroup per CU nothing overlaps the split with the MFMA phase.  (Round 1's attempt with a rounding split: 145-160.)
   // K = L1 runs along the inner index of both operands: A is zeroed past it, the table rows are clamped to F-1
   launch<true, true>(st, s, Mat{d_out, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, L1},
                      Mat{weight, (unsigned)((size_t)F * L1 * 4), L1, F - 1, kIntMax}, ValEpi{bits, d_conv_out, P}, B, P, L1);
@@ -1432,6 +1438,8 @@ int ftm_backward_impl(const uint8_t* bits, const float* sink, const float* d_out
   Shape sw3 = sw;  // bf16 weight-gradient tiles: bf_wm x 64 x 128
   if (bf_wm) { sw3.bm = bf_wm; sw3.bn = 64; sw3.bk = 128; sw3.tiles_m = (direct + bf_wm - 1) / bf_wm; sw3.tiles_n = (L1 + 63) / 64; }
   const Shape& swr = bf_wm ? sw3 : big_pair ? sw2 : sw;
+  // (value-gradient tiles of 32 x 32 x 128 -- twice the workgroups, two resident per CU -- were measured at the CIFAR
+  // batch-512 shape and lose: 30.5 vs 28.9 us for the launch)
   const Shape& svr = big_pair ? sv2 : sv;
   const int n_w = swr.tiles_m * swr.tiles_n, n_v = svr.tiles_m * svr.tiles_n, n_t = t.col_blocks * (1 + t.zero_slices);
   CwArgs cw{};

@@ -39,6 +39,7 @@ def dense_reference(conv_out, thr, weight, bias, d_out):
 SHAPES = [  # B, fps, Gh, Gw, F, L1: the CIFAR map (clamp sink), exact-fit map, table larger than the map, ragged everything
     (512, 8, 11, 11, 800, 1024), (64, 8, 11, 11, 800, 256), (37, 4, 8, 8, 256, 64), (5, 4, 3, 3, 100, 36),
     (16, 64, 8, 8, 4096, 128), (3, 2, 2, 1, 3, 4), (130, 8, 10, 10, 800, 200), (33, 12, 5, 5, 150, 72), (1, 4, 1, 1, 4, 8),
+    (24, 64, 32, 32, 65536, 256), (140, 64, 24, 24, 30000, 136),  # big maps: bf16-split tiles incl. the six-product value gradient
 ]
 
 
@@ -58,7 +59,12 @@ def test_ftm_kernels_against_float64(hip, shape, density):
     active = (conv_out > thr.view(1, -1, 1, 1)).reshape(b, -1)
     assert torch.equal(fm.n.cpu(), ref_n) and torch.equal(fm.sink.cpu(), ref_sink) and torch.equal(fm.bits.cpu(), active.to(torch.uint8))
     out = hip.ftm_forward(g(weight), g(bias), fm)
-    assert_close_logits(out, ref_out, "out", rtol=2e-5)
+    if fps * gh * gw >= 16384:
+        # sums of tens of thousands of float32 terms: an element near zero carries the rounding of partial sums of size
+        # sqrt(n) * 0.1, so the bar is taken against the tensor's scale (as for gradients), 1e-5 of it
+        assert_close_grad(out, ref_out, "out (big map)", rtol=1e-5)
+    else:
+        assert_close_logits(out, ref_out, "out", rtol=2e-5)
     d_w, d_b = hip.ftm_backward_weight(g(d_out), fm)
     assert_close_grad(d_w, ref_dw, "d_weight", rtol=2e-5)
     assert_close_grad(d_b, ref_db, "d_bias", rtol=2e-5)
