@@ -386,7 +386,9 @@ def main():
             blended = useful / t_mfma / 1e12  # the peak this launch could reach given which unit each product runs on
             achieved = useful / dur / 1e12 if dur > 0 else 0.0
             roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(blended, 1), "unit": "TFLOP/s",
-                        "frac": round(achieved / blended, 4), **common,
+                        "frac": round(achieved / blended, 4),
+                        "frac_of_f32_mfma_peak": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),  # round 1's pricing of the same launch, for comparison
+                        **common,
                         "regime": "useful flops of the products in the launch (2 M N K over the whole map) / HIP-event duration, against the "
                                   "peak of the unit each product runs on (f32-input MFMA 157.3 TF; bf16 MFMA 2.5 PF at three MFMAs per "
                                   "product for the exact split); table %.1f MB" % table_mb}

@@ -562,35 +562,26 @@ __device__ __forceinline__ void small_wgrad_body(const SmallWgrad& a, int blk) {
   const int lane = threadIdx.x & 63;
   const int v3 = (L3 % 4 == 0) ? 4 : 1, v2 = (L2 % 4 == 0) ? 4 : 1;
   const long long n_w3 = (long long)C * (L3 / v3), n_w2 = (long long)L3 * (L2 / v2);
-  const long long per = n_w3 + n_w2 + C + L3 + L2;  // outputs of one layer stack
-  int kb = 0, g_lo = 0, g_hi = B;
-  if (bk.rows) {
-    if (o < per * bk.K) {
-      kb = (int)(o / per);
-      o -= (long long)kb * per;
-      g_lo = bk.seg[kb];
-      g_hi = bk.seg[kb + 1];
-      d_w3 += (size_t)kb * C * L3; d_b3 += (size_t)kb * C; d_w2 += (size_t)kb * L3 * L2; d_b2 += (size_t)kb * L3; d_b1 += (size_t)kb * L2;
-    } else {
-      o = o - per * bk.K + per;  // the mean-loss wave behind the last stack
-    }
-  }
+  // A wave owns one group of outputs for EVERY layer stack: it walks the batch once in grouped order, bucket segment by
+  // segment, and stores that output of each stack (zeros for a stack without samples) -- the same loads as for one stack,
+  // no waves that find their bucket empty.  stride_k = distance of the same output between consecutive stacks.
   const float* pa;
   const float* pb = nullptr;
   int sa, sb = 0, vec = 1;
   float* dst;
+  size_t stride_k;
   if (o < n_w3) {
     const int c = (int)(o / (L3 / v3)), j = (int)(o % (L3 / v3)) * v3;
-    pa = d_logits + c; sa = C; pb = h2 + j; sb = L3; dst = d_w3 + (size_t)c * L3 + j; vec = v3;
+    pa = d_logits + c; sa = C; pb = h2 + j; sb = L3; dst = d_w3 + (size_t)c * L3 + j; vec = v3; stride_k = (size_t)C * L3;
   } else if ((o -= n_w3) < n_w2) {
     const int j = (int)(o / (L2 / v2)), k = (int)(o % (L2 / v2)) * v2;
-    pa = d_z2 + j; sa = L3; pb = h1 + k; sb = L2; dst = d_w2 + (size_t)j * L2 + k; vec = v2;
+    pa = d_z2 + j; sa = L3; pb = h1 + k; sb = L2; dst = d_w2 + (size_t)j * L2 + k; vec = v2; stride_k = (size_t)L3 * L2;
   } else if ((o -= n_w2) < C) {
-    pa = d_logits + o; sa = C; dst = d_b3 + o;
+    pa = d_logits + o; sa = C; dst = d_b3 + o; stride_k = C;
   } else if ((o -= C) < L3) {
-    pa = d_z2 + o; sa = L3; dst = d_b2 + o;
+    pa = d_z2 + o; sa = L3; dst = d_b2 + o; stride_k = L3;
   } else if ((o -= L3) < L2) {
-    pa = d_z1 + o; sa = L2; dst = d_b1 + o;
+    pa = d_z1 + o; sa = L2; dst = d_b1 + o; stride_k = L2;
   } else if (o == L2 && loss_out != nullptr) {  // one more wave: mean of the per-sample losses, fixed order
     float acc = 0.f;
     for (int b = lane; b < B; b += 64) acc += sample_loss[b];
@@ -600,36 +591,40 @@ __device__ __forceinline__ void small_wgrad_body(const SmallWgrad& a, int blk) {
   } else {
     return;
   }
-  if (vec == 4) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int stacks = bk.rows ? bk.K : 1;
+  for (int kb = 0; kb < stacks; ++kb, dst += stride_k) {
+    const int g_lo = bk.rows ? bk.seg[kb] : 0, g_hi = bk.rows ? bk.seg[kb + 1] : B;
+    if (vec == 4) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
-    for (int g = g_lo + lane; g < g_hi; g += 64) {
-      const int b = bk.rows ? bk.rows[g] : g;
-      if (b < 0) continue;
-      const float a = pa[(size_t)b * sa];
-      const float4 v = *reinterpret_cast<const float4*>(pb + (size_t)b * sb);
-      acc.x = fmaf(a, v.x, acc.x); acc.y = fmaf(a, v.y, acc.y); acc.z = fmaf(a, v.z, acc.z); acc.w = fmaf(a, v.w, acc.w);
+      for (int g = g_lo + lane; g < g_hi; g += 64) {
+        const int b = bk.rows ? bk.rows[g] : g;
+        if (b < 0) continue;
+        const float av = pa[(size_t)b * sa];
+        const float4 v = *reinterpret_cast<const float4*>(pb + (size_t)b * sb);
+        acc.x = fmaf(av, v.x, acc.x); acc.y = fmaf(av, v.y, acc.y); acc.z = fmaf(av, v.z, acc.z); acc.w = fmaf(av, v.w, acc.w);
+      }
+      acc.x = wave_sum(acc.x); acc.y = wave_sum(acc.y); acc.z = wave_sum(acc.z); acc.w = wave_sum(acc.w);
+      if (lane == 0) { dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z; dst[3] = acc.w; }
+      continue;
     }
-    acc.x = wave_sum(acc.x); acc.y = wave_sum(acc.y); acc.z = wave_sum(acc.z); acc.w = wave_sum(acc.w);
-    if (lane == 0) { dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z; dst[3] = acc.w; }
-    return;
-  }
-  float acc = 0.f;
-  if (pb) {
+    float acc = 0.f;
+    if (pb) {
 #pragma unroll 8
-    for (int g = g_lo + lane; g < g_hi; g += 64) {
-      const int b = bk.rows ? bk.rows[g] : g;
-      if (b >= 0) acc = fmaf(pa[(size_t)b * sa], pb[(size_t)b * sb], acc);
-    }
-  } else {
+      for (int g = g_lo + lane; g < g_hi; g += 64) {
+        const int b = bk.rows ? bk.rows[g] : g;
+        if (b >= 0) acc = fmaf(pa[(size_t)b * sa], pb[(size_t)b * sb], acc);
+      }
+    } else {
 #pragma unroll 8
-    for (int g = g_lo + lane; g < g_hi; g += 64) {
-      const int b = bk.rows ? bk.rows[g] : g;
-      if (b >= 0) acc += pa[(size_t)b * sa];
+      for (int g = g_lo + lane; g < g_hi; g += 64) {
+        const int b = bk.rows ? bk.rows[g] : g;
+        if (b >= 0) acc += pa[(size_t)b * sa];
+      }
     }
+    acc = wave_sum(acc);
+    if (lane == 0) *dst = acc;
   }
-  acc = wave_sum(acc);
-  if (lane == 0) *dst = acc;
 }
 
 __global__ __launch_bounds__(256) void small_wgrad_kernel(SmallWgrad a) { small_wgrad_body(a, (int)blockIdx.x); }
@@ -1054,7 +1049,7 @@ int backward_impl(const float* x, int pairwise, const float* w1, const float* w2
   hipLaunchKernelGGL(tail_backward_kernel, dim3(B), dim3(128), (size_t)(C + L3) * sizeof(float), s, d_logits, h1, h2, w2, w3,
                      clip, L2, L3, C, d_z1, d_z2, bk);
   {
-    const long long outs = K * ((long long)C * (L3 % 4 == 0 ? L3 / 4 : L3) + (long long)L3 * (L2 % 4 == 0 ? L2 / 4 : L2) + C + L3 + L2);
+    const long long outs = (long long)C * (L3 % 4 == 0 ? L3 / 4 : L3) + (long long)L3 * (L2 % 4 == 0 ? L2 / 4 : L2) + C + L3 + L2;  // per wave: all K stacks
     const SmallWgrad a{d_logits, d_z2, d_z1, h1, h2, B, L2, L3, C, d_w3, d_b3, d_w2, d_b2, d_b1, nullptr, nullptr, (int)((outs + 3) / 4),
                        nullptr, 0, 0ll, nullptr, bk, p.bww_klen};
     hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, s, a);
@@ -1229,7 +1224,7 @@ int train_step_impl(const float* x, int pairwise, const float* w1, const float* 
   const bool early_bww = (phases & 4) && p.bwx_mfma && p.bww_mfma && d_x != nullptr;
   const int tail_slabs = ext_slabs ? L1 / 64 : p.fwd_ksplit;
   // one launch: the small weight/bias gradients (per layer stack), the mean loss and (piggy-backed) the d_w1 slab sum
-  const long long outs = K * ((long long)C * (L3 % 4 == 0 ? L3 / 4 : L3) + (long long)L3 * (L2 % 4 == 0 ? L2 / 4 : L2) + C + L3 + L2) + 1;
+  const long long outs = (long long)C * (L3 % 4 == 0 ? L3 / 4 : L3) + (long long)L3 * (L2 % 4 == 0 ? L2 / 4 : L2) + C + L3 + L2 + 1;  // a wave serves all K stacks
   const int wgrad_blocks = (int)((outs + 3) / 4);
   const long long count = (long long)K * L2 * L1;
   const int slab_blocks = slab_pass && !ext_dw1 ? (int)((count / 4 + 255) / 256) : 0;

@@ -67,8 +67,11 @@ class TrainResult:
 def build_model(config, device):
     import nnue
     feature_set = nnue.GridFeatureSet(grid_size=config.grid_size, num_features_per_square=config.num_features_per_square)
+    # the two build extensions are read from the config when present (reference configs never set them: train.py:289-302)
     return nnue.NNUE(feature_set=feature_set, l1_size=config.l1_size, l2_size=config.l2_size, l3_size=config.l3_size,
-                     num_classes=config.num_classes, input_size=config.input_size, weight_decay=config.weight_decay).to(device)
+                     num_classes=config.num_classes, input_size=config.input_size, weight_decay=config.weight_decay,
+                     num_ls_buckets=int(getattr(config, "num_ls_buckets", 1)),
+                     clip_activations=getattr(config, "clip_activations", None)).to(device)
 
 
 def run_training(config, train_loader: Iterable, val_loader: Iterable, test_loader: Optional[Iterable] = None, model=None,

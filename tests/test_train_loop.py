@@ -169,3 +169,26 @@ def test_train_model_epochs_checkpoint_and_learning(tmp_path, opt):
     torch.save(ckpt["model_state_dict"], tmp_path / "bare.pt")
     serialize.serialize_model(serialize.load_model_from_checkpoint(tmp_path / "bare.pt"), tmp_path / "m.nnue")
     assert (tmp_path / "m.nnue").stat().st_size == orc.nnue_file_size(800, 8, 256, 32, 16, 10)
+
+
+@pytest.mark.gpu
+def test_train_model_with_bucketed_layer_stacks(tmp_path):
+    """The two build extensions read from the config module (num_ls_buckets, clip_activations): epochs, evaluation,
+    best-F1 checkpoint and export of a K = 4 model."""
+    path = write_config(tmp_path, opt="sgd", lr=0.02, epochs=2)
+    path.write_text(path.read_text() + "num_ls_buckets = 4\nclip_activations = 1.0\n")
+    cfg = train_loop.load_config(path)
+    train, val = make_loader(5, 16, 1, last=9), make_loader(2, 16, 2)
+    torch.manual_seed(0)
+    net = train_loop.build_model(cfg, "cuda")
+    assert net.num_ls_buckets == 4 and net.classifier.clip_activations == 1.0
+    res = train_loop.run_training(cfg, train, val, model=net, checkpoint_dir=tmp_path / "ckpt", log=lambda s: None)
+    assert res.steps == 2 * 6 and all(torch.isfinite(torch.tensor(r["train/epoch_loss"])) for r in res.history)
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    assert sd["classifier.classifier.0.weight"].shape == (4, 32, 256)
+    import serialize
+    torch.save(sd, tmp_path / "k4.pt")
+    model = serialize.load_model_from_checkpoint(tmp_path / "k4.pt")
+    assert model.num_ls_buckets == 4
+    serialize.serialize_model(model, tmp_path / "k4.nnue")
+    assert (tmp_path / "k4.nnue").stat().st_size == orc.nnue_file_size(800, 8, 256, 32, 16, 10, buckets=4)
