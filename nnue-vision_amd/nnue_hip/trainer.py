@@ -613,10 +613,17 @@ class NnueTrainer:
                 def full_dp(st):
                     self._run_local(slot, "all", st, branch=False)
                     self._exchange_and_update(False)
-                self._g_local[(slot, "full_dp")] = self._capture(full_dp)
-            self._g_local[(slot, "full_dp")].replay()
-            self.steps_done += 1
-            return self.loss
+                try:
+                    self._g_local[(slot, "full_dp")] = self._capture(full_dp)
+                except RuntimeError as exc:  # a stack that cannot capture its collectives: keep them eager from here on
+                    import warnings
+                    warnings.warn(f"collectives could not be captured into the step graph ({exc}); using the eager collective")
+                    self.capture_collectives = False
+                    torch.cuda.synchronize(self.dev)
+            if self.capture_collectives:
+                self._g_local[(slot, "full_dp")].replay()
+                self.steps_done += 1
+                return self.loss
         if graphs and not self.dp.collectives and not first and ragged is None:
             # single rank, steady state: local step + update are ONE graph (one replay per step)
             if (slot, "full") not in self._g_local:
