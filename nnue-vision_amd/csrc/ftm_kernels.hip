@@ -353,6 +353,15 @@ __device__ __forceinline__ void store_tile(float* __restrict__ smem, const Epi& 
   }
 }
 
+// streaming (non-temporal) 16-byte accesses: data touched once per step should not displace the L2's working set
+__device__ __forceinline__ float4 nt_load4(const float* p) {
+  const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void nt_store4(float* p, const float4& v) {
+  __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p));
+}
+
 template <class Epi, class = void>
 struct is_rmw { static constexpr bool value = false; };
 template <class Epi>
@@ -378,8 +387,8 @@ __device__ __forceinline__ void rmw_tile(float* __restrict__ smem, const Epi& ep
     const int m = m_base + row, n = n_base + 4 * c4;
     const bool ok = m < M && n < N;
     const size_t i = (size_t)m * epi.L1 + n;
-    w[u] = ok ? *reinterpret_cast<const float4*>(epi.weight + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-    mo[u] = (ok && epi.momentum && !epi.first_step) ? *reinterpret_cast<const float4*>(epi.momentum + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    w[u] = ok ? nt_load4(epi.weight + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    mo[u] = (ok && epi.momentum && !epi.first_step) ? nt_load4(epi.momentum + i) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -403,10 +412,9 @@ __device__ __forceinline__ void rmw_tile(float* __restrict__ smem, const Epi& ep
           g.x = fmaf(epi.mom, mo[u].x, g.x); g.y = fmaf(epi.mom, mo[u].y, g.y);
           g.z = fmaf(epi.mom, mo[u].z, g.z); g.w = fmaf(epi.mom, mo[u].w, g.w);
         }
-        *reinterpret_cast<float4*>(epi.momentum + i) = g;
+        nt_store4(epi.momentum + i, g);
       }
-      *reinterpret_cast<float4*>(epi.weight + i) = make_float4(w[u].x - epi.lr * g.x, w[u].y - epi.lr * g.y, w[u].z - epi.lr * g.z,
-                                                              w[u].w - epi.lr * g.w);
+      nt_store4(epi.weight + i, make_float4(w[u].x - epi.lr * g.x, w[u].y - epi.lr * g.y, w[u].z - epi.lr * g.z, w[u].w - epi.lr * g.w));
     }
   }
 }

@@ -24,3 +24,13 @@ for w in c1 c2 c3 c3k1; do python bench.py --workload $w --steps 300 --warmup 30
 python bench.py --workload c4 --steps 100 --warmup 10 > $O/bench_c4.json 2> $O/bench_c4.err || echo "bench c4 failed"
 python bench.py --workload c3 --spread --steps 300 --warmup 30 --no-cpu-baseline > $O/bench_c3_spread.json 2> $O/bench_c3_spread.err
 for w in c1 c2 c3 c3k1 c4; do cut -c1-220 $O/bench_$w.json; echo; done
+# density sweep: thresholds set over all slots and held (lr 0)
+for w in c2 c4; do for d in 0.01 0.05 0.25 0.9; do S=200; [ $w = c4 ] && S=50; python bench.py --workload $w --density $d --steps $S --warmup 10 --no-cpu-baseline > $O/dens_${w}_$d.json 2> $O/dens_${w}_$d.err || echo "density $w $d failed"; done; done
+python - <<PY
+import json, glob
+for f in sorted(glob.glob("$O/dens_*.json")):
+    try:
+        d = json.loads(open(f).read()); print(f.split("/")[-1], d["value"], d["config"]["active_density"], (d.get("gather_path") or {}).get("images_per_sec"))
+    except Exception as e:
+        print(f, "ERR", e)
+PY
