@@ -606,6 +606,7 @@ __device__ __forceinline__ void gemm_tile_bf(unsigned char* __restrict__ smem, c
   const int b_off = b_col(n_base + bn4) * 4;  // byte offset inside a row
   // A, forward (bytes contiguous along k): 16-byte groups, (row, 16 k); BM * 8 groups
   // A, weight gradient (bytes contiguous along m): thread = (k block of 8, m block of 4); BM / 4 x 16 blocks
+  const bool stream_b = mb.bytes > (64u << 20);  // uniform
   // (same 4 x 4 arrangement inside a 16-lane group as for the f32 operand: block index -> (m block, k block))
   auto a_block = [&](int g) {
     constexpr int MB = BM / 4;  // m blocks per k block
@@ -641,8 +642,15 @@ __device__ __forceinline__ void gemm_tile_bf(unsigned char* __restrict__ smem, c
           rat[i][j] = __builtin_amdgcn_raw_buffer_load_b32(rsa, on ? (k0 + k8 + j) * ma.ld + m_base + m4 : 0x7ffffff0, 0, 0);
       }
     }
+    // a table larger than the caches is streamed once per launch: non-temporal, so that it does not displace the map,
+    // d_out and the split-K slabs in L2
+    if (stream_b) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsb, (k0 + bk8 + j) * mb.ld * 4 + b_off, 0, 0);
+      for (int j = 0; j < 8; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsb, (k0 + bk8 + j) * mb.ld * 4 + b_off, 0, 2);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsb, (k0 + bk8 + j) * mb.ld * 4 + b_off, 0, 0);
+    }
   };
   auto stage = [&](const Regs& R) {
     const auto& ra = R.ra; const auto& rat = R.rat; const auto& rb = R.rb;
