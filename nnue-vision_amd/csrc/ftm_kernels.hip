@@ -166,7 +166,6 @@ struct FwdL1Epi {
   static constexpr bool kAU8 = true;
   static constexpr bool kFusedL1 = true;
   static constexpr bool kBPair = false;
-  static constexpr bool kSq = false;
   const float* __restrict__ bias;
   const float* __restrict__ w_last;
   const float* __restrict__ sink;
