@@ -238,3 +238,33 @@ def test_bucketed_trainer_step_against_the_oracle(monkeypatch, ride, use_graph):
         orc.sgd_step(params, g32, bufs, opt["lr"], opt["momentum"], opt["weight_decay"], opt["max_grad_norm"])
         for k in orc.TRAINABLE_KEYS:
             assert_close_grad(tr.p[k], params[k], f"step {s} parameter {k}", rtol=2e-5)
+
+
+def test_bucketed_trainer_with_the_fused_table_update_and_a_short_batch(monkeypatch):
+    """Combinations: K = 4 stacks + the table update inside the weight-gradient product (Gram norm) + a short last batch
+    (padded rows land in bucket 0 with label -1), against the oracle on the real samples."""
+    from nnue_hip.trainer import NnueTrainer
+    monkeypatch.setenv("NNUE_FUSE_TABLE_UPDATE", "1")
+    torch.manual_seed(6)
+    model = nnue.NNUE(nnue.GridFeatureSet(10, 8), 256, 32, 16, num_classes=10, num_ls_buckets=4, clip_activations=1.0)
+    with torch.no_grad():
+        model.conv.weight.abs_()
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    opt = dict(lr=0.05, momentum=0.9, weight_decay=1e-4, max_grad_norm=1.0)
+    tr = NnueTrainer(model, 64, (32, 32), use_graph=True, **opt)
+    assert tr.fuse_table_update and tr.K == 4 and not tr.ride_dw1
+    gen = torch.Generator().manual_seed(21)
+    bufs = {}
+    for s, n in enumerate((64, 64, 41)):
+        images = spread_images(n, 32, gen)
+        labels = torch.randint(0, 10, (n,), generator=gen)
+        p64 = {k: v.double() for k, v in params.items()}
+        _, ref_loss, ref_grads, _ = orc.loss_and_grads_explicit(p64, images.double(), labels, 3, 1.0)
+        loss = tr.step(images.to(DEV), labels.to(DEV))
+        assert abs(float(loss) - float(ref_loss)) <= 1e-4 * max(1.0, abs(float(ref_loss))), (s, float(loss), float(ref_loss))
+        ref_norm = orc.sgd_step(params, {k: v.float() for k, v in ref_grads.items()}, bufs, opt["lr"], opt["momentum"], opt["weight_decay"],
+                                opt["max_grad_norm"])
+        assert abs(float(tr.grad_norm) - float(ref_norm)) <= 1e-4 * float(ref_norm)
+        for k in orc.TRAINABLE_KEYS:
+            assert_close_grad(tr.p[k], params[k], f"step {s} parameter {k}", rtol=2e-5)
