@@ -223,8 +223,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
+    # set-up, outside warm-up and timing whatever --warmup says: the first step records the kernel plan, the following ones
+    # capture one hipGraph per input slot (with the collective inside when there are ranks)
+    for i in range(SLOTS + 1):
         trainer.step(slot=i % SLOTS)
+    for i in range(args.warmup):
+        trainer.step(slot=(i + 1) % SLOTS)
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
