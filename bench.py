@@ -250,7 +250,9 @@ def main():
     names = (["nnue_ftm_conv_binarize"] if trainer.use_mfma else
              ["nnue_conv3x3_forward", {"bits": "nnue_binarize_bits", "list": "nnue_binarize_features"}[trainer.ft_path]])
     fwd_entry = f"{ftp}_forward_l1" if getattr(trainer, "fuse_l1", False) else f"{ftp}_forward"  # fused: + layer-1 slabs in the epilogue
-    names += [fwd_entry] + (["nnue_bucket_group", "nnue_classifier_train_step_bucketed"] if trainer.K > 1 else ["nnue_classifier_train_step"])
+    if trainer.K > 1 and trainer.use_mfma:
+        fwd_entry = f"{ftp}_forward_grouping"  # + the bucket grouping as one extra workgroup of the launch
+    names += [fwd_entry] + (["nnue_classifier_train_step_bucketed"] if trainer.K > 1 else ["nnue_classifier_train_step"])
     # weight + value gradient (+ tail rows) go through one C call; it is one launch at launch-sized shapes and the two
     # separate launches at the 224x224 shapes (policy in nnue_ftm_backward)
     merged = trainer.use_mfma and trainer.merge_backward
@@ -295,7 +297,7 @@ def main():
     kernels = {k: {"avg_us": round(dur_us[k], 2), **({"alg_GBps": round(alg[k] / dur_us[k] * 1e-3, 1)} if k in alg and dur_us[k] > 0 else {})}
                for k in names}
     KERNEL_OF = {  # C entry point -> (kernel name prefix, substring) in rocprof / PMC summaries
-        "nnue_ftm_forward": ("ftm_gemm", "FwdEpi"), "nnue_ftm_forward_l1": ("ftm_forward_l1", ""),
+        "nnue_ftm_forward": ("ftm_gemm", "FwdEpi"), "nnue_ftm_forward_grouping": ("ftm_gemm", "FwdEpi"), "nnue_ftm_forward_l1": ("ftm_forward_l1", ""),
         "nnue_ftm_backward": ("ftm_backward", ""), "nnue_ftm_backward_bucketed": ("ftm_backward", ""),
         "nnue_ftm_backward_weight": ("ftm_gemm", "BwwEpi"), "nnue_ftm_backward_values": ("ftm_gemm", "ValEpi"),
         "nnue_ftm_backward_weight_update": ("ftm_gemm", "BwwSgdEpi"),
@@ -358,6 +360,7 @@ def main():
         tbl, mp, act = direct * L1 * 4.0, float(B * P), B * L1 * 4.0
         work = {  # entry -> ([(unit, useful flops)], compulsory bytes)
             f"{ftp}_forward": ([("bf16" if uses(0) else "f32", f_fwd)], tbl + mp + act),
+            f"{ftp}_forward_grouping": ([("bf16" if uses(0) else "f32", f_fwd)], tbl + mp + act),
             f"{ftp}_forward_l1": ([("bf16" if uses(0) else "f32", f_fwd), ("f32", f_l1)], tbl + mp + act + (L1 // 64) * B * L2 * 4.0),
             f"{ftp}_backward_weight": ([("bf16" if uses(1) else "f32", f_w)], mp + act + tbl),
             f"{ftp}_backward_values": ([("f32", f_v)], act + F * L1 * 4.0 + mp + B * P * 4.0),

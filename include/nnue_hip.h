@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 23
+#define NNUE_HIP_ABI_VERSION 24
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -342,6 +342,14 @@ int nnue_bucket_tile_count(int B, int K);
  * call.  K <= 64. */
 int nnue_bucket_group(const int32_t* n, int B, int P, int K, int32_t* bucket, int32_t* rows,
                       int32_t* tile_bucket, int32_t* seg, nnue_stream_t stream);
+
+/* nnue_ftm_forward (nnue.py:686-710) with nnue_bucket_group riding in the same launch as one extra workgroup: the grouping
+ * only needs the binarise kernel's counts n, like the product itself, so it costs no launch of its own.  Same outputs as
+ * the two calls. */
+int nnue_ftm_forward_grouping(const uint8_t* bits, const float* sink, const float* weight, const float* bias,
+                              int B, int F, int P, int L1, float* out, void* scratch, int64_t scratch_bytes,
+                              const int32_t* n, int K, int32_t* bucket, int32_t* rows, int32_t* tile_bucket,
+                              int32_t* seg, nnue_stream_t stream);
 
 /* nnue_classifier_forward / _backward / _train_step (nnue.py:660-666, :728-734 and their autograd) with stacked
  * weights and gradients [K][...] and the grouping above.  train_step: phases bits 8 and 16 are refused for K > 1

@@ -22,7 +22,7 @@ def stale() -> bool:
     if not OUT.exists():
         return True
     t = OUT.stat().st_mtime
-    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", ROOT / "include" / "nnue_hip.h", Path(__file__)]
+    deps = [CSRC / s for s in SOURCES] + sorted(CSRC.glob("*.h")) + [ROOT / "include" / "nnue_hip.h", Path(__file__)]
     return any(d.stat().st_mtime > t for d in deps)
 
 
@@ -32,7 +32,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     OBJ.mkdir(exist_ok=True)
-    shared = [CSRC / "common.h", ROOT / "include" / "nnue_hip.h", Path(__file__)]
+    shared = sorted(CSRC.glob("*.h")) + [ROOT / "include" / "nnue_hip.h", Path(__file__)]  # any header rebuilds every object
     newest_shared = max(d.stat().st_mtime for d in shared)
 
     def compile_one(src: str) -> Path:

@@ -870,7 +870,6 @@ struct ClsPlan {
   int bww_ksplit, bww_klen;  // batch slabs of d_w1
 };
 
-constexpr int kMaxBuckets = 64;
 int bucket_tiles(int B, int K) { return (B + 15) / 16 + K; }  // sum_k ceil(c_k / 16) <= B / 16 + K
 
 ClsPlan make_plan(int B, int L1, int L2, int pairwise, int K = 1) {
@@ -916,64 +915,12 @@ int64_t plan_scratch_floats(const ClsPlan& p, int B, int L1, int L2, int L3, int
 // ---- bucket selector + grouping (one workgroup; B a few thousand at most matters for speed, any B is correct) -----
 // bucket[b] = min(K-1, n[b] * K / (P + 1))  (P = flat ids of the map; P == 0: n[b] already IS the bucket, clamped)
 // then a stable counting sort of the samples into bucket-homogeneous 16-row tiles.
+#include "bucket_group.h"
+
 constexpr int kGroupThreads = 1024;  // one pass over a batch of 1024: every phase of the kernel is a latency, not work
-__global__ __launch_bounds__(kGroupThreads) void bucket_group_kernel(const int* __restrict__ n, int B, int P, int K,
-                                                                     int* __restrict__ bucket, int* __restrict__ rows,
-                                                                     int* __restrict__ tile_bucket, int* __restrict__ seg, int tiles) {
-  constexpr int NW = kGroupThreads / 64;
-  __shared__ int cnt[kMaxBuckets], start[kMaxBuckets + 1], run[kMaxBuckets], wtot[NW][kMaxBuckets];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  auto select = [&](int nb) {
-    int k = P > 0 ? (int)(((long long)nb * K) / ((long long)P + 1)) : nb;
-    k = k < 0 ? 0 : k;
-    return k < K - 1 ? k : K - 1;
-  };
-  const int first = tid < B ? select(n[tid]) : -1;  // this thread's sample of the first chunk (requested before anything else)
-  if (tid < K) { cnt[tid] = 0; run[tid] = 0; }
-  for (int i = tid; i < tiles * 16; i += kGroupThreads) rows[i] = -1;
-  __syncthreads();
-  for (int b = tid; b < B; b += kGroupThreads) {
-    const int k = b == tid ? first : select(n[b]);
-    bucket[b] = k;
-    atomicAdd(&cnt[k], 1);  // integer: exact in any order
-  }
-  __syncthreads();
-  if (tid == 0) {
-    start[0] = 0;
-    for (int k = 0; k < K; ++k) start[k + 1] = start[k] + (cnt[k] + 15) / 16 * 16;
-  }
-  __syncthreads();
-  if (tid <= K) seg[tid] = start[tid];
-  for (int t = tid; t < tiles; t += kGroupThreads) {
-    int kb = -1;
-    for (int k = 0; k < K; ++k)
-      if (16 * t >= start[k] && 16 * t < start[k] + cnt[k]) kb = k;
-    tile_bucket[t] = kb;
-  }
-  for (int chunk = 0; chunk < B; chunk += kGroupThreads) {  // stable: ascending sample index inside a bucket
-    const int b = chunk + tid;
-    const int k = chunk == 0 ? first : (b < B ? select(n[b]) : -1);
-    int rank = 0;
-    for (int kk = 0; kk < K; ++kk) {
-      const unsigned long long m = __ballot(k == kk);
-      if (lane == 0) wtot[wave][kk] = __popcll(m);
-      if (k == kk) rank = __popcll(m & ((1ull << lane) - 1ull));
-    }
-    __syncthreads();
-    if (k >= 0) {
-      int pre = 0;
-      for (int w = 0; w < wave; ++w) pre += wtot[w][k];
-      rows[start[k] + run[k] + pre + rank] = b;
-    }
-    if (chunk + kGroupThreads >= B) break;  // uniform
-    __syncthreads();
-    if (tid < K) {
-      int add = 0;
-      for (int w = 0; w < NW; ++w) add += wtot[w][tid];
-      run[tid] += add;
-    }
-    __syncthreads();
-  }
+__global__ __launch_bounds__(kGroupThreads) void bucket_group_kernel(GroupArgs ga) {
+  __shared__ int lds[kGroupLdsInts];
+  bucket_group_body<kGroupThreads>(ga, lds);
 }
 
 Buckets no_buckets() { return Buckets{1, nullptr, nullptr, nullptr, nullptr, 0}; }
@@ -1099,8 +1046,8 @@ extern "C" int nnue_bucket_group(const int32_t* n, int B, int P, int K, int32_t*
   NNUE_REQUIRE(n && bucket && rows && tile_bucket && seg, NNUE_E_ARG, "nnue_bucket_group: null pointer");
   NNUE_REQUIRE(B > 0 && P >= 0 && K >= 1, NNUE_E_ARG, "nnue_bucket_group: B=%d P=%d K=%d out of range", B, P, K);
   NNUE_REQUIRE(K <= kMaxBuckets, NNUE_E_SHAPE, "nnue_bucket_group: %d layer stacks (at most %d)", K, kMaxBuckets);
-  hipLaunchKernelGGL(bucket_group_kernel, dim3(1), dim3(kGroupThreads), 0, static_cast<hipStream_t>(stream), n, B, P, K, bucket, rows, tile_bucket,
-                     seg, bucket_tiles(B, K));
+  hipLaunchKernelGGL(bucket_group_kernel, dim3(1), dim3(kGroupThreads), 0, static_cast<hipStream_t>(stream),
+                     GroupArgs{n, B, P, K, bucket, rows, tile_bucket, seg, bucket_tiles(B, K)});
   return nnue_launch_status("nnue_bucket_group");
 }
 

@@ -29,6 +29,8 @@ namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+#include "bucket_group.h"  // the bucketed stacks' selector + grouping: rides as one extra workgroup of the forward launch
+
 // Row-major matrix seen as (outer, inner), read through a buffer descriptor: 16-byte loads at (outer, inner..inner+3),
 // hardware range check instead of branches -- rows past the end of the `bytes` window read as zero (that is how K
 // and M tails along the outer index vanish).  Rows past `clamp` read row `clamp` (ids >= F-1 share table row F-1);
@@ -761,8 +763,12 @@ __device__ __forceinline__ void gemm_tile_bf(unsigned char* __restrict__ smem, c
 }
 
 template <int BM, int BN, bool AKC, class Epi>
-__global__ __launch_bounds__(256) void ftm_gemm_bf_kernel(Mat ma, Mat mb, Epi epi, int M, int N, int K, int klen, int tiles_n) {
+__global__ __launch_bounds__(256) void ftm_gemm_bf_kernel(Mat ma, Mat mb, Epi epi, int M, int N, int K, int klen, int tiles_n, GroupArgs ga) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[gemm_bf_lds_bytes<BM, BN>()];
+  if (ga.n && blockIdx.x == gridDim.x - 1) {  // see ftm_gemm_kernel
+    if (blockIdx.y == 0) bucket_group_body<256>(ga, reinterpret_cast<int*>(smem));
+    return;
+  }
   const int k_lo = blockIdx.y * klen;
   gemm_tile_bf<BM, BN, AKC, Epi>(smem, ma, mb, epi, M, N, k_lo, (k_lo + klen < K) ? k_lo + klen : K, tiles_n, blockIdx.x, blockIdx.y);
 }
@@ -774,9 +780,17 @@ __global__ __launch_bounds__(256) void ftm_forward_l1_bf_kernel(Mat ma, Mat mb, 
   gemm_tile_bf<BM, 64, true, FwdL1Epi>(smem, ma, mb, epi, M, N, 0, K, tiles_n, blockIdx.x, 0);
 }
 
+// ga.n != NULL: the launch has one workgroup more than tiles (grid.x - 1 tiles); it groups the batch by layer-stack bucket
+// (bucket_group.h) -- work that only needs the binarise kernel's counts, like this product, and would otherwise be a launch
+// of its own between them.
 template <int BM, int BN, int BK, bool AKC, bool BKC, class Epi>
-__global__ __launch_bounds__(256) void ftm_gemm_kernel(Mat ma, Mat mb, Epi epi, int M, int N, int K, int klen, int tiles_n) {
+__global__ __launch_bounds__(256) void ftm_gemm_kernel(Mat ma, Mat mb, Epi epi, int M, int N, int K, int klen, int tiles_n, GroupArgs ga) {
   __shared__ __attribute__((aligned(16))) float smem[gemm_lds_floats<BM, BN, BK, AKC, BKC>()];
+  static_assert(gemm_lds_floats<BM, BN, BK, AKC, BKC>() >= kGroupLdsInts, "the grouping workgroup borrows the tile's LDS");
+  if (ga.n && blockIdx.x == gridDim.x - 1) {
+    if (blockIdx.y == 0) bucket_group_body<256>(ga, reinterpret_cast<int*>(smem));
+    return;
+  }
   const int k_lo = blockIdx.y * klen;
   gemm_tile<BM, BN, BK, AKC, BKC, Epi>(smem, ma, mb, epi, M, N, k_lo, (k_lo + klen < K) ? k_lo + klen : K, tiles_n, blockIdx.x, blockIdx.y);
 }
@@ -1200,10 +1214,10 @@ Shape plan(int M, int N, int K, bool prefer_m, bool allow_split, bool bf_ok = fa
 }
 
 template <bool AKC, bool BKC, class Epi>
-void launch(hipStream_t st, const Shape& s, Mat ma, Mat mb, Epi epi, int M, int N, int K) {
-  const dim3 grid((unsigned)(s.tiles_m * s.tiles_n), (unsigned)s.ksplit);
+void launch(hipStream_t st, const Shape& s, Mat ma, Mat mb, Epi epi, int M, int N, int K, GroupArgs ga = GroupArgs{}) {
+  const dim3 grid((unsigned)(s.tiles_m * s.tiles_n) + (ga.n ? 1u : 0u), (unsigned)s.ksplit);
 #define NNUE_FTM_LAUNCH(BM, BN, BK)                                                                                           \
-  hipLaunchKernelGGL((ftm_gemm_kernel<BM, BN, BK, AKC, BKC, Epi>), grid, dim3(256), 0, st, ma, mb, epi, M, N, K, s.klen, s.tiles_n)
+  hipLaunchKernelGGL((ftm_gemm_kernel<BM, BN, BK, AKC, BKC, Epi>), grid, dim3(256), 0, st, ma, mb, epi, M, N, K, s.klen, s.tiles_n, ga)
   switch (s.cfg) {
     case 0: NNUE_FTM_LAUNCH(32, 64, 128); break;
     case 1: NNUE_FTM_LAUNCH(64, 64, 64); break;
@@ -1214,7 +1228,7 @@ void launch(hipStream_t st, const Shape& s, Mat ma, Mat mb, Epi epi, int M, int 
     default:
       if constexpr (!BKC && Epi::kAU8) {  // bf16-split tiles: the map times an f32 operand that is contiguous along its rows
 #define NNUE_FTM_LAUNCH_BF(BM) \
-  hipLaunchKernelGGL((ftm_gemm_bf_kernel<BM, 64, AKC, Epi>), grid, dim3(256), 0, st, ma, mb, epi, M, N, K, s.klen, s.tiles_n)
+  hipLaunchKernelGGL((ftm_gemm_bf_kernel<BM, 64, AKC, Epi>), grid, dim3(256), 0, st, ma, mb, epi, M, N, K, s.klen, s.tiles_n, ga)
         if (s.cfg == 6) NNUE_FTM_LAUNCH_BF(32);
         else if (s.cfg == 7) NNUE_FTM_LAUNCH_BF(64);
         else NNUE_FTM_LAUNCH_BF(128);
@@ -1272,8 +1286,25 @@ extern "C" int nnue_ftm_binarize(const float* conv_out, const float* thr, int B,
   return nnue_launch_status("nnue_ftm_binarize");
 }
 
+namespace {
+int ftm_forward_impl(const uint8_t* bits, const float* sink, const float* weight, const float* bias, int B, int F, int P, int L1, float* out,
+                     void* scratch, int64_t scratch_bytes, GroupArgs ga, nnue_stream_t stream);
+}
 extern "C" int nnue_ftm_forward(const uint8_t* bits, const float* sink, const float* weight, const float* bias, int B, int F, int P,
                                 int L1, float* out, void* scratch, int64_t scratch_bytes, nnue_stream_t stream) {
+  return ftm_forward_impl(bits, sink, weight, bias, B, F, P, L1, out, scratch, scratch_bytes, GroupArgs{}, stream);
+}
+extern "C" int nnue_ftm_forward_grouping(const uint8_t* bits, const float* sink, const float* weight, const float* bias, int B, int F, int P,
+                                         int L1, float* out, void* scratch, int64_t scratch_bytes, const int32_t* n, int K, int32_t* bucket,
+                                         int32_t* rows, int32_t* tile_bucket, int32_t* seg, nnue_stream_t stream) {
+  NNUE_REQUIRE(n && bucket && rows && tile_bucket && seg, NNUE_E_ARG, "nnue_ftm_forward_grouping: null pointer");
+  NNUE_REQUIRE(K >= 1 && K <= kMaxBuckets && B > 0 && P > 0, NNUE_E_ARG, "nnue_ftm_forward_grouping: K=%d B=%d P=%d out of range", K, B, P);
+  return ftm_forward_impl(bits, sink, weight, bias, B, F, P, L1, out, scratch, scratch_bytes,
+                          GroupArgs{n, B, P, K, bucket, rows, tile_bucket, seg, (B + 15) / 16 + K}, stream);
+}
+namespace {
+int ftm_forward_impl(const uint8_t* bits, const float* sink, const float* weight, const float* bias, int B, int F, int P, int L1, float* out,
+                     void* scratch, int64_t scratch_bytes, GroupArgs ga, nnue_stream_t stream) {
   NNUE_REQUIRE(bits && sink && weight && bias && out, NNUE_E_ARG, "nnue_ftm_forward: null pointer");
   NNUE_REQUIRE(shape_ok(B, F, P, L1), NNUE_E_ARG, "nnue_ftm_forward: B=%d F=%d P=%d L1=%d out of range", B, F, P, L1);
   NNUE_REQUIRE(nnue_ftm_supported(F, P, L1), NNUE_E_SHAPE, "nnue_ftm_forward: P=%d and L1=%d must be multiples of 4", P, L1);
@@ -1291,7 +1322,7 @@ extern "C" int nnue_ftm_forward(const uint8_t* bits, const float* sink, const fl
   // A = the map (its K tail needs no zeroing: the table window ends at row `direct`, so B is zero there)
   launch<true, false>(st, s, Mat{bits, (unsigned)((size_t)B * P), P, kIntMax, kIntMax},
                       Mat{weight, (unsigned)((size_t)direct * L1 * 4), L1, kIntMax, kIntMax}, FwdEpi{bias, w_last, sink, dst, B, L1, s.ksplit}, B,
-                      L1, K);
+                      L1, K, ga);
   if (s.ksplit > 1) {
     const int64_t count4 = (int64_t)B * L1 / 4;
     hipLaunchKernelGGL(ftm_finish_kernel, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, st, dst, s.ksplit, count4, bias, w_last, sink,
@@ -1299,6 +1330,7 @@ extern "C" int nnue_ftm_forward(const uint8_t* bits, const float* sink, const fl
   }
   return nnue_launch_status("nnue_ftm_forward");
 }
+}  // namespace
 
 namespace {
 int backward_weight_impl(const uint8_t* bits, const float* sink, const float* d_out, int B, int F, int P, int L1, float* d_weight,

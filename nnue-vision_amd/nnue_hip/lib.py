@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -63,6 +63,8 @@ SIGNATURES = {
     "nnue_ftm_binarize": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p]),
     "nnue_ftm_conv_binarize": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "nnue_ftm_forward": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_i64, _c_p]),
+    "nnue_ftm_forward_grouping": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_i64, _c_p, _c_int,
+                                           _c_p, _c_p, _c_p, _c_p, _c_p]),
     "nnue_ftm_forward_l1_supported": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int]),
     "nnue_ftm_forward_l1": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
     "nnue_ftm_backward_weight": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
@@ -624,7 +626,9 @@ def ftm_conv_binarize(images: torch.Tensor, weight: torch.Tensor, thr: torch.Ten
     return conv_out, fm
 
 
-def ftm_forward(weight: torch.Tensor, bias: torch.Tensor, fm: FeatureMatrix, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def ftm_forward(weight: torch.Tensor, bias: torch.Tensor, fm: FeatureMatrix, out: Optional[torch.Tensor] = None,
+                group=None) -> torch.Tensor:
+    """group (a BucketPlan): the bucket grouping of this batch (from fm.n) rides in the launch as one extra workgroup."""
     weight = _need(weight, torch.float32, "input.weight")
     f, l1 = weight.shape
     bias = _need(bias, torch.float32, "input.bias", (l1,))
@@ -632,8 +636,15 @@ def ftm_forward(weight: torch.Tensor, bias: torch.Tensor, fm: FeatureMatrix, out
         raise ValueError("ftm_forward: the map was built for a different table")
     if out is None:
         out = torch.empty((fm.batch, l1), dtype=torch.float32, device=weight.device)
-    _call("nnue_ftm_forward", fm.bits.data_ptr(), fm.sink.data_ptr(), weight.data_ptr(), bias.data_ptr(), fm.batch, f,
-          fm.positions, l1, out.data_ptr(), fm.scratch.data_ptr(), fm.scratch.numel(), _stream(weight))
+    args = (fm.bits.data_ptr(), fm.sink.data_ptr(), weight.data_ptr(), bias.data_ptr(), fm.batch, f,
+            fm.positions, l1, out.data_ptr(), fm.scratch.data_ptr(), fm.scratch.numel())
+    if group is None:
+        _call("nnue_ftm_forward", *args, _stream(weight))
+    else:
+        if group.batch != fm.batch:
+            raise ValueError("ftm_forward: the bucket plan was built for another batch size")
+        _call("nnue_ftm_forward_grouping", *args, fm.n.data_ptr(), group.K, group.bucket.data_ptr(), group.rows.data_ptr(),
+              group.tile_bucket.data_ptr(), group.seg.data_ptr(), _stream(weight))
     return out
 
 

@@ -368,9 +368,10 @@ class NnueTrainer:
             if self.use_bits:
                 lib.binarize_bits(self.conv_out, p["visual_threshold"], self.F, self.L1, bits=self.bits, stages=2)
         elif name == "forward":
-            if self.bucket_plan is not None:  # stack of each sample from the counts the binarise kernel just wrote
-                feats = self.fm if self.use_mfma else self.bits if self.use_bits else self.act
+            if self.bucket_plan is not None and not self.use_mfma:  # stack of each sample from the counts the binarise kernel just wrote
+                feats = self.bits if self.use_bits else self.act
                 lib.bucket_group(feats.n, self.P, self.K, plan=self.bucket_plan)
+            # (product form: the grouping rides in the FeatureTransformer forward launch as one extra workgroup)
             if self.use_mfma and self.fuse_l1:
                 # the forward's epilogue also forms the classifier's layer-1 slabs (start of its scratch)
                 lib.ftm_forward_l1(p["input.weight"], p["input.bias"], self.fm, p["classifier.classifier.0.weight"], self.cls_scratch,
@@ -378,7 +379,7 @@ class NnueTrainer:
                 self._cls_step(27 if self.ride_dw1 else 13)  # 27: both phases, d_w1 left to the merged backward
                 return
             if self.use_mfma:
-                lib.ftm_forward(p["input.weight"], p["input.bias"], self.fm, out=self.ft)
+                lib.ftm_forward(p["input.weight"], p["input.bias"], self.fm, out=self.ft, group=self.bucket_plan)
             elif self.use_bits:
                 lib.ftb_forward(p["input.weight"], p["input.bias"], self.bits, out=self.ft)
             else:

@@ -268,3 +268,21 @@ def test_bucketed_trainer_with_the_fused_table_update_and_a_short_batch(monkeypa
         assert abs(float(tr.grad_norm) - float(ref_norm)) <= 1e-4 * float(ref_norm)
         for k in orc.TRAINABLE_KEYS:
             assert_close_grad(tr.p[k], params[k], f"step {s} parameter {k}", rtol=2e-5)
+
+
+@pytest.mark.parametrize("shape", ((512, 8, 11, 11, 800, 1024, 8), (100, 64, 32, 32, 65536, 256, 4), (37, 4, 8, 8, 256, 64, 3)))
+def test_grouping_riding_in_the_forward_launch(shape):
+    """nnue_ftm_forward_grouping: the same ft as nnue_ftm_forward (bitwise) and the same plan as nnue_bucket_group."""
+    b, fps, gh, gw, f, l1, K = shape
+    gen = torch.Generator().manual_seed(b + K)
+    conv_out = torch.randn(b, fps, gh, gw, generator=gen) + torch.linspace(-1.5, 1.5, b).view(b, 1, 1, 1)
+    thr = torch.full((fps,), 0.1)
+    weight, bias = (torch.randn(f, l1, generator=gen) * 0.1).to(DEV), torch.randn(l1, generator=gen).to(DEV)
+    fm = lib.ftm_binarize(conv_out.to(DEV), thr.to(DEV), f, l1)
+    want = lib.bucket_group(fm.n, fps * gh * gw, K)
+    plan = lib.BucketPlan(b, K, DEV)
+    out = lib.ftm_forward(weight, bias, fm, group=plan)
+    assert torch.equal(out, lib.ftm_forward(weight, bias, fm))
+    for name in ("bucket", "rows", "tile_bucket", "seg"):
+        assert torch.equal(getattr(plan, name), getattr(want, name)), name
+    assert len(set(plan.bucket.tolist())) >= 2
