@@ -813,7 +813,15 @@ __global__ __launch_bounds__(256) void ftm_finish_kernel(const float* __restrict
   const float s = sink[e / L1];
   const float4 bv = *reinterpret_cast<const float4*>(bias + n), wv = *reinterpret_cast<const float4*>(w_last + n);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int k = 0; k < ksplit; ++k) {
+  int k = 0;
+  for (; k + 8 <= ksplit; k += 8) {  // eight slabs in flight, summed in slab order
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(partial + (size_t)(k + u) * count4 * 4 + e);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+  }
+  for (; k < ksplit; ++k) {
     const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)k * count4 * 4 + e);
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
   }
