@@ -61,6 +61,9 @@ def parse():
                     help="bucketed workloads: give every sample its own offset and gain (and make the conv weights positive) so "
                          "that the active-feature counts, and with them the layer-stack buckets, cover the whole range; default "
                          "randn images put nearly every sample into one bucket")
+    ap.add_argument("--steps-per-graph", type=int, default=8,
+                    help="consecutive steps (each on the next input slot) replayed as one hipGraph (NnueTrainer.step_many); "
+                         "steps left over after the whole groups run as single-step graphs; 1 = one graph launch per step")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather-compare", action="store_true",
@@ -225,21 +228,35 @@ def main():
 
     # set-up, outside warm-up and timing whatever --warmup says: the first step records the kernel plan, the following ones
     # capture one hipGraph per input slot (with the collective inside when there are ranks)
-    for i in range(SLOTS + 1):
-        trainer.step(slot=i % SLOTS)
-    for i in range(args.warmup):
-        trainer.step(slot=(i + 1) % SLOTS)
+    S = max(1, args.steps_per_graph)
+
+    def run_steps(tr, n):
+        """n optimizer steps, step i on input slot i % SLOTS; whole groups of S steps as one graph replay."""
+        i = 0
+        while S > 1 and i + S <= n:
+            tr.step_many(tuple((i + j) % SLOTS for j in range(S)))
+            i += S
+        for j in range(i, n):
+            tr.step(slot=j % SLOTS)
+
+    def set_up(tr):
+        for i in range(SLOTS + 1):
+            tr.step(slot=i % SLOTS)
+        if S > 1:
+            run_steps(tr, S * SLOTS)  # captures the S-step graph of every slot rotation the loops below replay
+
+    set_up(trainer)
+    run_steps(trainer, args.warmup)
     sync()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        trainer.step(slot=i % SLOTS)
+    run_steps(trainer, args.steps)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss_after = float(trainer.loss)
+    loss_after = float(trainer.loss) if S == 1 or args.steps % S else float(trainer.loss_ring[S - 1])
     n_mean, n_max = trainer.active_stats()
     bucket_hist = (torch.bincount(trainer.bucket_plan.bucket.long(), minlength=trainer.K).tolist()
                    if trainer.bucket_plan is not None else None)
@@ -431,12 +448,11 @@ def main():
                     gi.copy_(si)
                     gl.copy_(sl)
                 gsteps = max(10, min(args.steps, 100))
-                for i in range(max(5, min(args.warmup, 20))):
-                    tg.step(slot=i % SLOTS)
+                set_up(tg)
+                run_steps(tg, max(5, min(args.warmup, 20)))
                 torch.cuda.synchronize(dev)
                 tg0 = time.perf_counter()
-                for i in range(gsteps):
-                    tg.step(slot=i % SLOTS)
+                run_steps(tg, gsteps)
                 torch.cuda.synchronize(dev)
                 g_elapsed = time.perf_counter() - tg0
                 gn_mean, _ = tg.active_stats()
@@ -496,7 +512,7 @@ def main():
                                       f"(build extension, parity unpinned), " if cfg.get("buckets", 1) > 1 else "")
                                    + ("per-sample offset/gain spread, " if args.spread else "")
                                    + f"batch {B}/GPU, SGD m0.9 wd2e-4 clip1.0" + (f", thresholds set for density {args.density} and held (lr 0)" if args.density is not None else ""),
-                       "global_batch": B * world, "parallelism": f"dp{world}", "launch": "eager" if args.no_graph else "hipGraph",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "launch": "eager" if args.no_graph else "hipGraph", "steps_per_graph": S,
                        "mean_active_features": round(n_mean, 1), "max_active_features": n_max,
                        "active_density": round(n_mean / ((cfg["image"] - 1) // max(1, (cfg["image"] - 1) // (cfg["grid"] - 1)) + 1) ** 2 / cfg["fps"], 4),
                        "eager_ms_per_step_instrumented": round(eager_ms, 4), "loss_after": round(loss_after, 4),

@@ -94,7 +94,7 @@ def run_training(config, train_loader: Iterable, val_loader: Iterable, test_load
     else:
         opt = dict(optimizer="adam")
     trainer = NnueTrainer(model, batch, hw, lr=float(config.learning_rate), weight_decay=float(config.weight_decay),
-                          max_grad_norm=clip, use_graph=use_graph, input_slots=2 if in_place else 1, **opt)
+                          max_grad_norm=clip, use_graph=use_graph, input_slots=8 if in_place else 1, **opt)
     result = TrainResult()
     ckpt_dir = Path(checkpoint_dir) if checkpoint_dir is not None else None
     for epoch in range(int(config.max_epochs)):

@@ -53,6 +53,20 @@ def _worker(rank, port, out_dir, world, backend, use_graph, env, short_last):
         assert tr.capture_collectives == (backend == "nccl" and use_graph and env.get("NNUE_DP_CAPTURE", "1") != "0")
         sl = tr.dp.shard(GLOBAL_BATCH)
         losses = []
+        if env.get("TEST_STEP_MANY") == "1":  # steps 0, 1 singly (plan, then graph), steps 2 and 3 as ONE graph with both exchanges inside
+            for s in range(STEPS):
+                images, labels = _batch(s)
+                tr.inputs[s % 2][0].copy_(images[sl])
+                tr.inputs[s % 2][1].copy_(labels[sl])
+                if s < 2:
+                    losses.append(float(tr.step(slot=s % 2)))
+                elif s == 3:
+                    torch.cuda.synchronize()
+                    losses += [float(v) for v in tr.step_many((0, 1))]
+                    assert ((0, 1), "many") in tr._g_local or not tr.capture_collectives
+            torch.cuda.synchronize()
+            torch.save({"flat": tr.flat_params.cpu(), "norm": float(tr.grad_norm), "losses": losses}, Path(out_dir) / f"rank{rank}.pt")
+            return
         for s in range(STEPS):
             images, labels = _batch(s)
             if short_last and s == STEPS - 1:  # the global batch holds SHORT real samples; the last rank(s) come up short
@@ -123,8 +137,14 @@ def test_one_rank_over_rccl_with_the_collective_inside_the_graph(tmp_path, env):
     _run(tmp_path, 1, "nccl", True, {"NNUE_DP_FORCE_COLLECTIVES": "1", **env})
 
 
+def test_one_rank_over_rccl_two_steps_in_one_graph(tmp_path):
+    """step_many under collectives: two consecutive steps, each with its all-reduce, captured and replayed as one hipGraph."""
+    _run(tmp_path, 1, "nccl", True, {"NNUE_DP_FORCE_COLLECTIVES": "1", "TEST_STEP_MANY": "1"})
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI between ranks)")
 @pytest.mark.parametrize("env", ({}, {"NNUE_DP_SHARDED_UPDATE": "1"}, {"NNUE_DP_CAPTURE": "0"}))
 def test_two_ranks_over_rccl(tmp_path, env):
     _run(tmp_path, 2, "nccl", True, env)
     _run(tmp_path, 2, "nccl", True, env, short_last=True)
+    _run(tmp_path, 2, "nccl", True, {**env, "TEST_STEP_MANY": "1"})

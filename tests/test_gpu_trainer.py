@@ -167,3 +167,40 @@ def test_first_step_on_another_slot_leaves_slot_zero_alone_and_lr_changes_take_e
         ref.step(*data[slot])
     assert_close_grad(tr.flat_params, ref.flat_params, "parameters after an lr change", rtol=1e-6)
     assert_close_grad(tr.evaluate(data[1][0]), ref.evaluate(data[1][0]), "evaluate after a plan recorded on slot 2", rtol=1e-6)
+
+
+@pytest.mark.parametrize("shape", ("small", "buckets"))
+def test_step_many_is_the_same_steps_in_one_graph(shape):
+    """step_many((s0, s1, ...)) replays the kernels of step(slot=s0), step(slot=s1), ... as one hipGraph: bitwise the same
+    parameters, momentum and per-step losses; a learning-rate change drops the captured graph."""
+    kw = dict(num_ls_buckets=4, clip_activations=1.0) if shape == "buckets" else {}
+    torch.manual_seed(0)
+    model = nnue.NNUE(nnue.GridFeatureSet(10, 8), 256, 32, 16, num_classes=10, **kw).to(DEV)
+    twin = nnue.NNUE(nnue.GridFeatureSet(10, 8), 256, 32, 16, num_classes=10, **kw).to(DEV)
+    twin.load_state_dict(model.state_dict())
+    gen = torch.Generator().manual_seed(5)
+    data = [(torch.randn(64, 3, 32, 32, generator=gen).to(DEV), torch.randint(0, 10, (64,), generator=gen).to(DEV)) for _ in range(3)]
+    opt = dict(lr=0.05, momentum=0.9, weight_decay=1e-4, max_grad_norm=1.0, input_slots=3, use_graph=True)
+    tr, ref = NnueTrainer(model, 64, (32, 32), **opt), NnueTrainer(twin, 64, (32, 32), **opt)
+    for t in (tr, ref):
+        for (im, lb), (ti, tl) in zip(data, t.inputs):
+            ti.copy_(im)
+            tl.copy_(lb)
+    order = (0, 1, 2, 1, 0)
+    first = tr.step_many(order[:2])  # before anything is recorded: falls back to single steps
+    want = [ref.step(slot=s).clone() for s in order[:2]]
+    assert torch.equal(first, torch.stack(want))
+    for rep in range(2):
+        got = tr.step_many(order).clone()
+        want = torch.stack([ref.step(slot=s).clone() for s in order])
+        assert torch.equal(got, want), (rep, got, want)
+    assert (order, "many") in tr._g_local and tr.steps_done == ref.steps_done == 12
+    tr.lr = ref.lr = 0.2
+    assert (order, "many") not in tr._g_local
+    got = tr.step_many(order).clone()
+    want = torch.stack([ref.step(slot=s).clone() for s in order])
+    assert torch.equal(got, want)
+    assert torch.equal(tr.flat_params, ref.flat_params)
+    assert torch.equal(tr.flat_momentum, ref.flat_momentum)
+    with pytest.raises(ValueError):
+        tr.step_many((0, 3))

@@ -34,9 +34,9 @@ def main():
     batches = [order[i * b:(i + 1) * b] for i in range(n // b)]
     torch.manual_seed(0)
     model = nnue.NNUE(nnue.GridFeatureSet(10, 8), 1024, 128, 32, num_classes=10).cuda()
-    tr = NnueTrainer(model, b, (32, 32), lr=0.01, momentum=0.9, weight_decay=2e-4, max_grad_norm=1.0, input_slots=2)
+    tr = NnueTrainer(model, b, (32, 32), lr=0.01, momentum=0.9, weight_decay=2e-4, max_grad_norm=1.0, input_slots=8)
     out, lab = tr.inputs[0]
-    res = {"dataset": [n, 32, 32, 3], "batch": b}
+    res = {"dataset": [n, 32, 32, 3], "batch": b, "input_slots": 8}
     for name, ds in (("plain", ds_plain), ("light_aug", ds_aug)):
         fn = lambda i: ds.batch(batches[i % len(batches)], out=out, labels_out=lab)
         timed(fn, 50)
