@@ -8,6 +8,7 @@
 // shape allows (L1 % 32 == 0, L2 % 16 == 0), split over K so that >= 512 waves are in flight, and
 // on plain-VALU "simple" kernels otherwise.  The two narrow layers (L2 -> L3 -> C) are a per-sample
 // tail kernel working out of LDS.  Split-K partials are summed in fixed order: reproducible.
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -506,10 +507,10 @@ __global__ __launch_bounds__(128) void tail_backward_kernel(const float* __restr
   }
 }
 
-// Small batch reductions; lanes stride over the batch, one wave per group of outputs:
-//   d_w3 [C, L3] | d_w2 [L3, L2]   four adjacent columns per wave (one float4 load feeds four sums; needs
-//                                   L3 % 4 == 0 resp. L2 % 4 == 0, else one column per wave)
-//   d_b3 [C] | d_b2 [L3] | d_b1 [L2]  one output per wave
+// Small batch reductions, one workgroup per 16 x 16 output tile (f32 MFMA, K = the batch):
+//   d_w3 [C, L3] = d_logits^T h2 | d_w2 [L3, L2] = d_z2^T h1 | d_b3 [C] | d_b2 [L3] | d_b1 [L2] = column sums
+// (The earlier form -- one wave per four outputs, lanes striding over the batch -- touched one cache line per lane and
+// load: 9.1 us at the CIFAR batch-512 shape, the longest part of the d_x launch it rides in.)
 struct SmallWgrad {
   const float *d_logits, *d_z2, *d_z1, *h1, *h2;
   int B, L2, L3, C;
@@ -558,73 +559,118 @@ __device__ __forceinline__ void small_wgrad_body(const SmallWgrad& a, int blk) {
     *reinterpret_cast<float4*>(d_w1 + i) = acc;
     return;
   }
-  long long o = (long long)blk * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const int v3 = (L3 % 4 == 0) ? 4 : 1, v2 = (L2 % 4 == 0) ? 4 : 1;
-  const long long n_w3 = (long long)C * (L3 / v3), n_w2 = (long long)L3 * (L2 / v2);
-  // A wave owns one group of outputs for EVERY layer stack: it walks the batch once in grouped order, bucket segment by
-  // segment, and stores that output of each stack (zeros for a stack without samples) -- the same loads as for one stack,
-  // no waves that find their bucket empty.  stride_k = distance of the same output between consecutive stacks.
-  const float* pa;
-  const float* pb = nullptr;
-  int sa, sb = 0, vec = 1;
-  float* dst;
-  size_t stride_k;
-  if (o < n_w3) {
-    const int c = (int)(o / (L3 / v3)), j = (int)(o % (L3 / v3)) * v3;
-    pa = d_logits + c; sa = C; pb = h2 + j; sb = L3; dst = d_w3 + (size_t)c * L3 + j; vec = v3; stride_k = (size_t)C * L3;
-  } else if ((o -= n_w3) < n_w2) {
-    const int j = (int)(o / (L2 / v2)), k = (int)(o % (L2 / v2)) * v2;
-    pa = d_z2 + j; sa = L3; pb = h1 + k; sb = L2; dst = d_w2 + (size_t)j * L2 + k; vec = v2; stride_k = (size_t)L3 * L2;
-  } else if ((o -= n_w2) < C) {
-    pa = d_logits + o; sa = C; dst = d_b3 + o; stride_k = C;
-  } else if ((o -= C) < L3) {
-    pa = d_z2 + o; sa = L3; dst = d_b2 + o; stride_k = L3;
-  } else if ((o -= L3) < L2) {
-    pa = d_z1 + o; sa = L2; dst = d_b1 + o; stride_k = L2;
-  } else if (o == L2 && loss_out != nullptr) {  // one more wave: mean of the per-sample losses, fixed order
-    float acc = 0.f;
-    for (int b = lane; b < B; b += 64) acc += sample_loss[b];
-    acc = wave_sum(acc);
-    if (lane == 0) *loss_out = acc / (float)B;
-    return;
-  } else {
-    return;
-  }
+  // One workgroup per 16 x 16 output tile of out[m][n] = sum_b A[b][m] * Bm[b][n] on the f32 MFMA: the batch is walked in
+  // chunks of 16 rows, chunk c by wave c % 4 (64-byte runs of each operand row per load instead of one line per lane), the
+  // four waves' accumulators are added in wave order through LDS.  Bias gradients are the same tile with A == 1 (row 0 is
+  // the column sum).  With layer stacks there is one workgroup per (tile, stack), contracting that stack's grouped rows
+  // (zeros for a stack without samples).
+  __shared__ float red[4][256];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int t3n = (L3 + 15) / 16, t2n = (L2 + 15) / 16, tcm = (C + 15) / 16;
+  const int n_w3 = tcm * t3n, n_w2 = t3n * t2n;
   const int stacks = bk.rows ? bk.K : 1;
-  for (int kb = 0; kb < stacks; ++kb, dst += stride_k) {
-    const int g_lo = bk.rows ? bk.seg[kb] : 0, g_hi = bk.rows ? bk.seg[kb + 1] : B;
-    if (vec == 4) {
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-      for (int g = g_lo + lane; g < g_hi; g += 64) {
-        const int b = bk.rows ? bk.rows[g] : g;
-        if (b < 0) continue;
-        const float av = pa[(size_t)b * sa];
-        const float4 v = *reinterpret_cast<const float4*>(pb + (size_t)b * sb);
-        acc.x = fmaf(av, v.x, acc.x); acc.y = fmaf(av, v.y, acc.y); acc.z = fmaf(av, v.z, acc.z); acc.w = fmaf(av, v.w, acc.w);
-      }
-      acc.x = wave_sum(acc.x); acc.y = wave_sum(acc.y); acc.z = wave_sum(acc.z); acc.w = wave_sum(acc.w);
-      if (lane == 0) { dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z; dst[3] = acc.w; }
-      continue;
+  const int kb = blk % stacks;  // a workgroup forms its tile for ONE layer stack
+  int t = blk / stacks;
+  const float* A;
+  const float* Bm;
+  float* dst;
+  int lda = 0, ldb, ldd = 0, M, N, m0 = 0, n0;
+  size_t stride_k;
+  if (t < n_w3) {
+    A = d_logits; lda = C; Bm = h2; ldb = L3; dst = d_w3; ldd = L3; M = C; N = L3; m0 = (t / t3n) * 16; n0 = (t % t3n) * 16; stride_k = (size_t)C * L3;
+  } else if ((t -= n_w3) < n_w2) {
+    A = d_z2; lda = L3; Bm = h1; ldb = L2; dst = d_w2; ldd = L2; M = L3; N = L2; m0 = (t / t2n) * 16; n0 = (t % t2n) * 16; stride_k = (size_t)L3 * L2;
+  } else if ((t -= n_w2) < tcm) {
+    A = nullptr; Bm = d_logits; ldb = C; dst = d_b3; M = 1; N = C; n0 = t * 16; stride_k = C;
+  } else if ((t -= tcm) < t3n) {
+    A = nullptr; Bm = d_z2; ldb = L3; dst = d_b2; M = 1; N = L3; n0 = t * 16; stride_k = L3;
+  } else if ((t -= t3n) < t2n) {
+    A = nullptr; Bm = d_z1; ldb = L2; dst = d_b1; M = 1; N = L2; n0 = t * 16; stride_k = L2;
+  } else {
+    if (t == t2n && kb == 0 && loss_out != nullptr && wave == 0) {  // one more workgroup: mean of the per-sample losses, fixed order
+      float acc = 0.f;
+      for (int b = lane; b < B; b += 64) acc += sample_loss[b];
+      acc = wave_sum(acc);
+      if (lane == 0) *loss_out = acc / (float)B;
     }
-    float acc = 0.f;
-    if (pb) {
-#pragma unroll 8
-      for (int g = g_lo + lane; g < g_hi; g += 64) {
-        const int b = bk.rows ? bk.rows[g] : g;
-        if (b >= 0) acc = fmaf(pa[(size_t)b * sa], pb[(size_t)b * sb], acc);
-      }
-    } else {
-#pragma unroll 8
-      for (int g = g_lo + lane; g < g_hi; g += 64) {
-        const int b = bk.rows ? bk.rows[g] : g;
-        if (b >= 0) acc += pa[(size_t)b * sa];
-      }
-    }
-    acc = wave_sum(acc);
-    if (lane == 0) *dst = acc;
+    return;
   }
+  const bool m_ok = m0 + r < M, n_ok = n0 + r < N;
+  const int mc = m_ok ? m0 + r : 0, nc = n_ok ? n0 + r : 0;  // clamped: every load below is unconditional and in range
+  dst += (size_t)kb * stride_k;
+  {
+    const int g_lo = bk.rows ? bk.seg[kb] : 0, g_hi = bk.rows ? bk.seg[kb + 1] : B;
+    const int nch = (g_hi - g_lo + 15) / 16;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 4;  // chunks of loads in flight per wave
+    // straight-line load batches (no branch around a load: a conditional load drags an s_waitcnt vmcnt(0) behind it):
+    // rows beyond the segment / padding rows read row 0 and are multiplied out
+    auto chunk_batch = [&](int c0, auto rows_tag, auto ones_tag) {
+      constexpr bool ROWS = decltype(rows_tag)::value, ONES = decltype(ones_tag)::value;
+      int bi[U][4];
+      bool ok[U][4];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int g = g_lo + 16 * (c0 + 4 * u) + 4 * q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ok[u][e] = g + e < g_hi;
+          const int gi = ok[u][e] ? g + e : g_lo;
+          bi[u][e] = ROWS ? bk.rows[gi] : gi;
+        }
+      }
+      float av[U][4], bv[U][4];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (ROWS) ok[u][e] = ok[u][e] && bi[u][e] >= 0;
+          const int b = ok[u][e] ? bi[u][e] : 0;
+          av[u][e] = ONES ? 1.0f : A[(size_t)b * lda + mc];
+          bv[u][e] = Bm[(size_t)b * ldb + nc];
+        }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a_ = (ONES || (ok[u][e] && m_ok)) ? av[u][e] : 0.0f;
+          const float b_ = (ok[u][e] && n_ok) ? bv[u][e] : 0.0f;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b_, acc, 0, 0, 0);
+        }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    if (bk.rows) {
+      if (A) for (int c0 = wave; c0 < nch; c0 += 4 * U) chunk_batch(c0, T{}, F{});
+      else for (int c0 = wave; c0 < nch; c0 += 4 * U) chunk_batch(c0, T{}, T{});
+    } else {
+      if (A) for (int c0 = wave; c0 < nch; c0 += 4 * U) chunk_batch(c0, F{}, F{});
+      else for (int c0 = wave; c0 < nch; c0 += 4 * U) chunk_batch(c0, F{}, T{});
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wave][lane * 4 + e] = acc[e];
+    __syncthreads();
+    if (wave == 0 && n_ok) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = lane * 4 + e, m = m0 + 4 * q + e;
+        const float v = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+        if (A) {
+          if (m < M) dst[(size_t)m * ldd + n0 + r] = v;
+        } else if (4 * q + e == 0) {
+          dst[n0 + r] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// number of output tiles of small_wgrad_body's five families; the launch takes tiles * K workgroups (+ 1 for the mean loss)
+inline int small_wgrad_tiles(int L2, int L3, int C) {
+  const int t3 = (L3 + 15) / 16, t2 = (L2 + 15) / 16, tc = (C + 15) / 16;
+  return tc * t3 + t3 * t2 + tc + t3 + t2;
 }
 
 __global__ __launch_bounds__(256) void small_wgrad_kernel(SmallWgrad a) { small_wgrad_body(a, (int)blockIdx.x); }
@@ -996,10 +1042,10 @@ int backward_impl(const float* x, int pairwise, const float* w1, const float* w2
   hipLaunchKernelGGL(tail_backward_kernel, dim3(B), dim3(128), (size_t)(C + L3) * sizeof(float), s, d_logits, h1, h2, w2, w3,
                      clip, L2, L3, C, d_z1, d_z2, bk);
   {
-    const long long outs = (long long)C * (L3 % 4 == 0 ? L3 / 4 : L3) + (long long)L3 * (L2 % 4 == 0 ? L2 / 4 : L2) + C + L3 + L2;  // per wave: all K stacks
-    const SmallWgrad a{d_logits, d_z2, d_z1, h1, h2, B, L2, L3, C, d_w3, d_b3, d_w2, d_b2, d_b1, nullptr, nullptr, (int)((outs + 3) / 4),
+    const int tiles = small_wgrad_tiles(L2, L3, C) * K;  // no mean loss here
+    const SmallWgrad a{d_logits, d_z2, d_z1, h1, h2, B, L2, L3, C, d_w3, d_b3, d_w2, d_b2, d_b1, nullptr, nullptr, tiles,
                        nullptr, 0, 0ll, nullptr, bk, p.bww_klen};
-    hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)tiles), dim3(256), 0, s, a);
   }
   if (p.bww_mfma) {
     const long long waves = (long long)K * (L2 / 32) * (L1 / 64) * p.bww_ksplit;
@@ -1171,8 +1217,7 @@ int train_step_impl(const float* x, int pairwise, const float* w1, const float* 
   const bool early_bww = (phases & 4) && p.bwx_mfma && p.bww_mfma && d_x != nullptr;
   const int tail_slabs = ext_slabs ? L1 / 64 : p.fwd_ksplit;
   // one launch: the small weight/bias gradients (per layer stack), the mean loss and (piggy-backed) the d_w1 slab sum
-  const long long outs = (long long)C * (L3 % 4 == 0 ? L3 / 4 : L3) + (long long)L3 * (L2 % 4 == 0 ? L2 / 4 : L2) + C + L3 + L2 + 1;  // a wave serves all K stacks
-  const int wgrad_blocks = (int)((outs + 3) / 4);
+  const int wgrad_blocks = small_wgrad_tiles(L2, L3, C) * K + 1;  // one workgroup per (tile, stack) + the mean loss
   const long long count = (long long)K * L2 * L1;
   const int slab_blocks = slab_pass && !ext_dw1 ? (int)((count / 4 + 255) / 256) : 0;
   const SmallWgrad sw{d_logits, d_z2, d_z1, h1, h2, B, L2, L3, C, d_w3, d_b3, d_w2, d_b2, d_b1, sample_loss, loss, wgrad_blocks,
