@@ -186,6 +186,22 @@ __global__ __launch_bounds__(256) void sgd_apply_kernel(float* __restrict__ p, c
                                                         int ext_count, float* __restrict__ coef_out, int64_t skip_lo, int64_t skip_hi) {
   __shared__ double red[4];
   __shared__ float coef_s;
+  // The first kPre passes of this thread's share are requested BEFORE the norm is re-derived: after a kernel boundary
+  // both the partials and the parameters are first touches (~2 us each from a cold L2), and the two waits would
+  // otherwise run one after the other.  Unconditional loads from clamped indices; results used only where valid.
+  constexpr int kPre = 4;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t hole = skip_hi - skip_lo;  // 0: everything is updated here
+  const int64_t live = count - hole, j0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float pw[kPre], pg[kPre], pm[kPre];
+#pragma unroll
+  for (int u = 0; u < kPre; ++u) {
+    const int64_t j = j0 + u * stride < live ? j0 + u * stride : 0;
+    const int64_t i = j < skip_lo ? j : j + hole;
+    pw[u] = p[i];
+    pg[u] = g[i];
+    pm[u] = (m && !first_step) ? m[i] : 0.0f;
+  }
   float clip = 1.0f;
   if (max_norm > 0.0f || norm_out || coef_out) {
     double acc = 0.0;
@@ -208,9 +224,20 @@ __global__ __launch_bounds__(256) void sgd_apply_kernel(float* __restrict__ p, c
     clip = coef_s;
   }
   const float gs = clip * scale;
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  const int64_t hole = skip_hi - skip_lo;  // 0: everything is updated here
-  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < count - hole; j += stride) {
+#pragma unroll
+  for (int u = 0; u < kPre; ++u) {
+    const int64_t j = j0 + u * stride;
+    if (j < live) {
+      const int64_t i = j < skip_lo ? j : j + hole;
+      float gi = fmaf(wd, pw[u], pg[u] * gs);
+      if (m) {
+        gi = first_step ? gi : fmaf(momentum, pm[u], gi);
+        m[i] = gi;
+      }
+      p[i] = pw[u] - lr * gi;
+    }
+  }
+  for (int64_t j = j0 + kPre * stride; j < live; j += stride) {
     const int64_t i = j < skip_lo ? j : j + hole;
     const float w = p[i];
     float gi = fmaf(wd, w, g[i] * gs);
