@@ -61,9 +61,10 @@ def parse():
                     help="bucketed workloads: give every sample its own offset and gain (and make the conv weights positive) so "
                          "that the active-feature counts, and with them the layer-stack buckets, cover the whole range; default "
                          "randn images put nearly every sample into one bucket")
-    ap.add_argument("--steps-per-graph", type=int, default=8,
+    ap.add_argument("--steps-per-graph", type=int, default=0,
                     help="consecutive steps (each on the next input slot) replayed as one hipGraph (NnueTrainer.step_many); "
-                         "steps left over after the whole groups run as single-step graphs; 1 = one graph launch per step")
+                         "steps left over after the whole groups run as single-step graphs; 1 = one graph launch per step; "
+                         "0 (default) = the group size in 5..16 that leaves the fewest single steps for --steps")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather-compare", action="store_true",
@@ -228,7 +229,9 @@ def main():
 
     # set-up, outside warm-up and timing whatever --warmup says: the first step records the kernel plan, the following ones
     # capture one hipGraph per input slot (with the collective inside when there are ranks)
-    S = max(1, args.steps_per_graph)
+    S = args.steps_per_graph
+    if S <= 0:  # fewest left-over single steps, then the larger group
+        S = min(range(5, 17), key=lambda g: (args.steps % g, -g)) if args.steps >= 5 else 1
 
     def run_steps(tr, n):
         """n optimizer steps, step i on input slot i % SLOTS; whole groups of S steps as one graph replay."""

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 24
+#define NNUE_HIP_ABI_VERSION 25
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -397,13 +397,17 @@ int nnue_classifier_train_step_bucketed(const float* x, int pairwise,
  * gives the table's share from two B x B Gram matrices without forming the [direct][L1] gradient.
  * nnue_ftm_gram_sqnorm leaves nnue_ftm_gram_sq_count(B, L1) partial sums (unscaled; sum = that squared norm, formed as
  * sum (G_A D) . D so that D D^T is not needed either) for nnue_sgd_step(ext_partial, ..., coef_out,
- * ext_applied_elsewhere = 1); gram is [B*B] floats of scratch.  nnue_ftm_backward_tail_rows forms the rows the product does not cover (d_bias, row F-1, zero
+ * ext_applied_elsewhere = 1); gram is nnue_ftm_gram_scratch(B, F, P) floats of scratch whose first B*B hold A A^T afterwards
+ * (formed on the i8 matrix unit straight from the byte map; K slices leave int32 slabs behind it, added in slice order:
+ * no atomics, nothing to clear).  nnue_ftm_backward_tail_rows forms the rows the product does not cover (d_bias, row F-1, zero
  * rows: what nnue_ftm_backward_weight adds to its product).  nnue_ftm_backward_weight_update then runs the product
  * d_W = A^T d_out (autograd of nnue.py:702-708) and, element by element in its epilogue, the optimizer's update
  *     g = coef[0]*grad_scale*d_W + wd*w ;  m = first_step ? g : momentum*m + g ;  w -= lr*m       (train.py:457-464)
  * on table rows [0, direct) -- the same arithmetic nnue_sgd_step applies -- so d_weight is never written or read back
  * (268 MB each way at the 224x224 configuration).  momentum_rows may be NULL when momentum == 0. */
 int64_t nnue_ftm_gram_sq_count(int B, int L1);
+/* floats of scratch behind nnue_ftm_gram_sqnorm's gram pointer (clip_grad_norm_, train.py:363-366: see above) */
+int64_t nnue_ftm_gram_scratch(int B, int F, int P);
 int nnue_ftm_gram_sqnorm(const uint8_t* bits, const float* d_out, int B, int F, int P, int L1,
                          float* gram, float* sq_partial, nnue_stream_t stream);
 /* (autograd of nnue.py:691, :701-708 for the bias row and the clamp-sink row F-1) */

@@ -1031,89 +1031,115 @@ __global__ __launch_bounds__(256) void ftm_binarize_kernel(const float* __restri
 //   sum_{f,n} (sum_b A_bf D_bn)^2 = sum_{b,b'} (A A^T)_{bb'} (D D^T)_{bb'}
 // -- two B x B Gram matrices instead of the [direct][L1] gradient, which lets clip_grad_norm_ (train.py:363-366) know
 // its norm before that gradient exists, so the product that forms it can apply the update in its epilogue (BwwSgdEpi).
-// A A^T: counts of common active positions -- integers < 2^24, exact in f32 and in any order, so K slices add their
-// 128 x 128 tiles with float atomics into a matrix a zero-fill kernel clears first.
-__global__ __launch_bounds__(256) void gram_a_kernel(const uint8_t* __restrict__ bits, unsigned bytes, int B, int P, int direct, int klen,
-                                                     int tiles_b, float* __restrict__ G) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 128 * kBfK * 2];
-  unsigned char* __restrict__ Ms = smem;
-  unsigned char* __restrict__ Ns = smem + 128 * kBfK * 2;
+// A A^T: counts of common active positions, on the i8 matrix unit straight from the byte map.  Lane l of
+// v_mfma_i32_16x16x64_i8 holds 16 consecutive k of row l & 15 for both operands -- exactly a 16-byte load of a map row, so
+// there is no LDS image and no conversion; both operands are fetched the same way, so whatever order the instruction
+// gives the 64 k of a step, the two sides agree.  A workgroup owns one 32 x 32 tile pair (tm >= tn: the matrix is
+// symmetric) and one K slice, its four waves a quarter of the slice each; their accumulators are added through LDS and
+// stored as one int32 slab, and gram_finish_kernel adds the slabs in slice order and writes both mirror positions.
+// (The first form -- bf16 MFMA over LDS images, 128 x 128 tiles in 128 slices added with float atomics into a zeroed
+// matrix -- spent 12.8 of its 23.5 us at the 224x224 shape on 2 M atomic additions into one 64 KB matrix; 64 x 64 tiles
+// over more workgroups only moved the same additions around: 21-50 us for 1-4 M of them.)
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+constexpr int kGramU = 4;  // 64-k steps whose loads are issued together
+
+__device__ __forceinline__ void gram_pair(int x, int& tm, int& tn) {  // x enumerates the pairs tm >= tn
+  tm = 0;
+  while ((tm + 1) * (tm + 2) / 2 <= x) ++tm;
+  tn = x - tm * (tm + 1) / 2;
+}
+
+__global__ __launch_bounds__(256) void gram_i8_kernel(const uint8_t* __restrict__ bits, unsigned bytes, int B, int P, int direct, int wave_steps,
+                                                      int* __restrict__ slabs) {
+  __shared__ int red[4][4][256];
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(bits), 0, bytes, 0x00020000);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
-  const int tm = blockIdx.x / tiles_b, tn = blockIdx.x % tiles_b;
-  if (tn > tm) return;  // symmetric: the mirror tile is written from this one
-  const int m_base = tm * 128, n_base = tn * 128;
-  const int k_lo = blockIdx.y * klen, k_hi = (k_lo + klen < direct) ? k_lo + klen : direct;
-  const int m0 = (wave >> 1) * 64, n0 = (wave & 1) * 64;
-  u32x4 rm[4], rn[4];
-  auto fetch = [&](int k0) {
+  int tm, tn;
+  gram_pair((int)blockIdx.x, tm, tn);
+  const bool diag = tm == tn;  // uniform
+  const int row_m = (tm * 32 + r) * P, row_n = (tn * 32 + r) * P;  // rows beyond the batch lie beyond the buffer: they read as zero
+  const int k_lo = ((int)blockIdx.y * 4 + wave) * wave_steps * 64;
+  const int k_end = (direct + 63) & ~63;
+  const int k_hi = k_lo + wave_steps * 64 < k_end ? k_lo + wave_steps * 64 : k_end;
+  i32x4 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int g = tid + 256 * i, row = g >> 3, k = k0 + (g & 7) * 16;
-      rm[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (m_base + row) * P + k, 0, 0);
-      rn[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (n_base + row) * P + k, 0, 0);
-    }
-  };
-  auto put = [&](unsigned char* img, const u32x4& raw, int row, int c, int k) {  // bytes at k .. k+15, only those below direct count
-    u32x4 lo, hi;
-    unsigned w[4];
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[i][t] = (i32x4){0, 0, 0, 0};
+  auto clip = [&](i32x4 v, int k) {  // bytes at k .. k + 15 of a row: those at or beyond `direct` do not count
+    i32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int valid = direct - (k + 4 * j);
-      w[j] = valid >= 4 ? raw[j] : valid <= 0 ? 0u : (raw[j] & ((1u << (8 * valid)) - 1u));
+      o[j] = valid >= 4 ? v[j] : valid <= 0 ? 0 : (int)((unsigned)v[j] & ((1u << (8 * valid)) - 1u));
     }
-    unsigned a, b;
-    bytes_to_bf16(w[0], a, b); lo[0] = a; lo[1] = b;
-    bytes_to_bf16(w[1], a, b); lo[2] = a; lo[3] = b;
-    bytes_to_bf16(w[2], a, b); hi[0] = a; hi[1] = b;
-    bytes_to_bf16(w[3], a, b); hi[2] = a; hi[3] = b;
-    *reinterpret_cast<u32x4*>(img + bf_img(row, c)) = lo;
-    *reinterpret_cast<u32x4*>(img + bf_img(row, c + 1)) = hi;
+    return o;
   };
-  f32x4 acc[4][4];
+  for (int k0 = k_lo; k0 < k_hi; k0 += 64 * kGramU) {
+    i32x4 am[kGramU][2], an[kGramU][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int u = 0; u < kGramU; ++u) {
+      const int k = k0 + 64 * u + 16 * q;
+      const bool in = k0 + 64 * u < k_hi;  // uniform; a step past the slice reads beyond the buffer (zeros)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  fetch(k_lo);
-  for (int k0 = k_lo; k0 < k_hi; k0 += kBfK) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int g = tid + 256 * i, row = g >> 3, c = (g & 7) * 2;
-      put(Ms, rm[i], row, c, k0 + (g & 7) * 16);
-      put(Ns, rn[i], row, c, k0 + (g & 7) * 16);
+      for (int i = 0; i < 2; ++i) {
+        am[u][i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, in ? row_m + 16 * i * P + k : 0x7ffffff0, 0, 0));
+        if (!diag) an[u][i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, in ? row_n + 16 * i * P + k : 0x7ffffff0, 0, 0));
+      }
     }
-    __syncthreads();
-    if (k0 + kBfK < k_hi) fetch(k0 + kBfK);
 #pragma unroll
-    for (int kb = 0; kb < kBfK / 32; ++kb) {
-      const int c = kb * 4 + q;
-      bf16x8 a[4], b[4];
+    for (int u = 0; u < kGramU; ++u) {
+      const int k = k0 + 64 * u + 16 * q;
+      if (k0 + 64 * u + 64 > direct) {  // uniform: the step that holds position `direct`
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(Ms + bf_img(m0 + 16 * i + r, c));
-#pragma unroll
-      for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const bf16x8*>(Ns + bf_img(n0 + 16 * t + r, c));
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int m = m_base + m0 + 16 * i + 4 * q + e, n = n_base + n0 + 16 * t + r;
-        if (m < B && n < B && acc[i][t][e] != 0.0f) {
-          atomicAdd(&G[(size_t)m * B + n], acc[i][t][e]);
-          if (tn != tm) atomicAdd(&G[(size_t)n * B + m], acc[i][t][e]);
+        for (int i = 0; i < 2; ++i) {
+          am[u][i] = clip(am[u][i], k);
+          if (!diag) an[u][i] = clip(an[u][i], k);
         }
       }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          acc[i][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(am[u][i], diag ? am[u][t] : an[u][t], acc[i][t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wave][i * 2 + t][lane * 4 + e] = acc[i][t][e];
+  __syncthreads();
+  int* __restrict__ out = slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 1024;
+#pragma unroll
+  for (int tile = 0; tile < 4; ++tile) out[tile * 256 + tid] = (red[0][tile][tid] + red[1][tile][tid]) + (red[2][tile][tid] + red[3][tile][tid]);
+}
+
+// G[m][n] = G[n][m] = sum over the K slices of the pair's slab element; grid (pairs * 4): one workgroup per 16 x 16 sub-tile
+__global__ __launch_bounds__(256) void gram_finish_kernel(const int* __restrict__ slabs, int pairs, int slices, int B, float* __restrict__ G) {
+  const int pair = blockIdx.x >> 2, tile = blockIdx.x & 3, tid = threadIdx.x;
+  int tm, tn;
+  gram_pair(pair, tm, tn);
+  const int* __restrict__ src = slabs + (size_t)pair * 1024 + tile * 256 + tid;
+  int acc = 0, sl = 0;
+  for (; sl + 8 <= slices; sl += 8) {
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(sl + u) * pairs * 1024];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; sl < slices; ++sl) acc += src[(size_t)sl * pairs * 1024];
+  // slab element [tile = 2 i + t][lane * 4 + e]: accumulator register e of lane 16 q + r is row 4 q + e, column r
+  const int ln = tid >> 2, e = tid & 3, i = tile >> 1, t = tile & 1;
+  const int m = tm * 32 + 16 * i + 4 * (ln >> 4) + e, n = tn * 32 + 16 * t + (ln & 15);
+  if (m < B && n < B) {
+    G[(size_t)m * B + n] = (float)acc;
+    if (tm != tn) G[(size_t)n * B + m] = (float)acc;
+  }
 }
 
 // sum_{b,b'} G_A[b][b'] (D D^T)[b][b'] = sum_{b,n} (G_A D)[b][n] D[b][n]: one wave per 16 x 16 tile of T = G_A D (f32 MFMA,
@@ -1563,6 +1589,30 @@ extern "C" int nnue_ftm_forward_l1(const uint8_t* bits, const float* sink, const
 // ---- the table's weight gradient consumed in place (single rank + SGD; see BwwSgdEpi and the Gram kernels) ----------
 extern "C" int64_t nnue_ftm_gram_sq_count(int B, int L1) { return (B > 0 && L1 > 0) ? (int64_t)((B + 15) / 16) * ((L1 + 15) / 16) : 0; }
 
+namespace {
+// K slicing of the A A^T product: about 512 workgroups, every wave at least four 64-k steps (a multiple of four: one
+// batch of loads), slices = workgroups per tile pair
+struct GramPlan { int pairs, slices, wave_steps; };
+GramPlan gram_plan(int B, int direct) {
+  const int tiles_b = (B + 31) / 32, pairs = tiles_b * (tiles_b + 1) / 2;
+  const int steps = direct > 0 ? (direct + 63) / 64 : 1;
+  static const int want_wgs = env_int("NNUE_FTM_GRAM_WGS", 512);  // developer knob
+  int want = want_wgs / pairs;
+  want = want < 1 ? 1 : want;
+  int per = (steps + want * 4 - 1) / (want * 4);
+  per = ((per + 3) / 4) * 4;
+  const int slices = (steps + per * 4 - 1) / (per * 4);
+  return GramPlan{pairs, slices, per};
+}
+}  // namespace
+
+// floats of scratch nnue_ftm_gram_sqnorm needs behind `gram`: the B x B matrix, then the K slices' int32 slabs
+extern "C" int64_t nnue_ftm_gram_scratch(int B, int F, int P) {
+  if (B <= 0 || F <= 1 || P <= 0) return 0;
+  const GramPlan g = gram_plan(B, (F - 1 < P) ? F - 1 : P);
+  return (int64_t)B * B + (int64_t)g.pairs * g.slices * 1024;
+}
+
 extern "C" int nnue_ftm_gram_sqnorm(const uint8_t* bits, const float* d_out, int B, int F, int P, int L1, float* gram, float* sq_partial,
                                     nnue_stream_t stream) {
   NNUE_REQUIRE(bits && d_out && gram && sq_partial, NNUE_E_ARG, "nnue_ftm_gram_sqnorm: null pointer");
@@ -1572,16 +1622,14 @@ extern "C" int nnue_ftm_gram_sqnorm(const uint8_t* bits, const float* d_out, int
   NNUE_REQUIRE(nnue_aligned16(bits) && nnue_aligned16(d_out), NNUE_E_ARG, "nnue_ftm_gram_sqnorm: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int direct = (F - 1 < P) ? F - 1 : P;
-  const int tiles_b = (B + 127) / 128, lower = tiles_b * (tiles_b + 1) / 2;
-  const int ktiles = (direct + kBfK - 1) / kBfK;
-  nnue_zero_floats(gram, (size_t)B * B, st);
+  const GramPlan g = gram_plan(B, direct);
+  int* slabs = reinterpret_cast<int*>(gram + (size_t)B * B);
   if (direct > 0) {
-    int slices = 128 / lower;
-    slices = slices < 1 ? 1 : (slices > ktiles ? ktiles : slices);
-    const int per = (ktiles + slices - 1) / slices;
-    slices = (ktiles + per - 1) / per;
-    hipLaunchKernelGGL(gram_a_kernel, dim3((unsigned)(tiles_b * tiles_b), (unsigned)slices), dim3(256), 0, st, bits, (unsigned)((size_t)B * P), B, P,
-                       direct, per * kBfK, tiles_b, gram);
+    hipLaunchKernelGGL(gram_i8_kernel, dim3((unsigned)g.pairs, (unsigned)g.slices), dim3(256), 0, st, bits, (unsigned)((size_t)B * P), B, P, direct,
+                       g.wave_steps, slabs);
+    hipLaunchKernelGGL(gram_finish_kernel, dim3((unsigned)(g.pairs * 4)), dim3(256), 0, st, (const int*)slabs, g.pairs, g.slices, B, gram);
+  } else {
+    nnue_zero_floats(gram, (size_t)B * B, st);
   }
   const int64_t tiles16 = nnue_ftm_gram_sq_count(B, L1);
   hipLaunchKernelGGL(gram_apply_kernel, dim3((unsigned)((tiles16 + 3) / 4)), dim3(256), 0, st, gram, d_out, B, L1, sq_partial);

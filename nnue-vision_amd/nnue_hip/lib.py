@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -118,6 +118,7 @@ SIGNATURES = {
     "nnue_ftm_uses_bf16": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int]),
     "nnue_sqnorm_partials": (_c_int, [_c_p, _c_i64, _c_p, _c_int, _c_p]),
     "nnue_ftm_gram_sq_count": (_c_i64, [_c_int, _c_int]),
+    "nnue_ftm_gram_scratch": (_c_i64, [_c_int, _c_int, _c_int]),
     "nnue_ftm_gram_sqnorm": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
     "nnue_ftm_backward_tail_rows": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
     "nnue_ftm_backward_weight_update": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_f, _c_f, _c_f, _c_f,
@@ -955,11 +956,17 @@ def sqnorm_partials(grads: torch.Tensor, partial: torch.Tensor) -> torch.Tensor:
     return partial
 
 
+def ftm_gram_scratch(fm: "FeatureMatrix") -> int:
+    """Floats of scratch ftm_gram_sqnorm needs for this map."""
+    return int(load().nnue_ftm_gram_scratch(fm.bits.shape[0], fm.num_rows, fm.positions))
+
+
 def ftm_gram_sqnorm(fm: "FeatureMatrix", d_out: torch.Tensor, gram: torch.Tensor, sq_partial: torch.Tensor) -> torch.Tensor:
-    """Partial sums of ||A^T d_out||_F^2 over the table rows the map reaches, from two B x B Gram matrices."""
+    """Partial sums of ||A^T d_out||_F^2 over the table rows the map reaches, from two B x B Gram matrices.  ``gram``:
+    ``ftm_gram_scratch(fm)`` floats of scratch; its first B*B hold A A^T afterwards."""
     d_out = _need(d_out, torch.float32, "d_out")
     b, l1 = d_out.shape
-    _need(gram, torch.float32, "gram", (b, b))
+    _need(gram, torch.float32, "gram scratch", (ftm_gram_scratch(fm),))
     _need(sq_partial, torch.float32, "gram partials", (int(load().nnue_ftm_gram_sq_count(b, l1)),))
     _call("nnue_ftm_gram_sqnorm", fm.bits.data_ptr(), d_out.data_ptr(), b, fm.num_rows, fm.positions, l1, gram.data_ptr(),
           sq_partial.data_ptr(), _stream(d_out))

@@ -291,7 +291,7 @@ class NnueTrainer:
             self.ride_dw1 = False  # the rider lives in the merged launch, which this path does not use
             self.sq_partial = torch.empty((int(lib.load().nnue_ftm_gram_sq_count(B, self.L1)),), **f32)
             self.sq_range = (off, off + rows * self.L1)
-            self.gram = torch.zeros((B, B), **f32)
+            self.gram = torch.zeros((lib.ftm_gram_scratch(self.fm),), **f32)
             self.clip_coef = torch.ones((), **f32)
         self.grads_materialised = not self.fuse_table_update
         self.d_z1 = self.ft_rider = None

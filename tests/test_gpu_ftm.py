@@ -334,13 +334,13 @@ def test_gram_form_of_the_weight_gradient_norm(hip, shape):
     direct = min(f - 1, fps * gh * gw)
     a = (conv_out > 0.17).reshape(b, -1)[:, :direct].double()
     ref = float(((a.t() @ d_out.double()) ** 2).sum())
-    gram = torch.zeros(b, b, device=DEV)
+    gram = torch.full((hip.ftm_gram_scratch(fm),), float("nan"), device=DEV)  # nothing in the scratch needs clearing
     part = torch.empty(int(hip.load().nnue_ftm_gram_sq_count(b, l1)), device=DEV)
-    for _ in range(2):  # the scratch is cleared by the call itself
+    for _ in range(2):
         hip.ftm_gram_sqnorm(fm, d_out.to(DEV), gram, part)
         got = float(part.double().sum())
         assert abs(got - ref) <= 2e-6 * ref, (got, ref)
-    assert torch.equal(gram.cpu().double(), a @ a.t())  # common active positions: exact integers
+    assert torch.equal(gram[:b * b].view(b, b).cpu().double(), a @ a.t())  # common active positions: exact integers
 
 
 def test_table_update_in_the_product_epilogue_equals_the_materialised_path(hip, monkeypatch):
