@@ -115,6 +115,7 @@ struct BwwSgdEpi {
   int L1;
   float lr, mom, wd, scale;
   int first_step;
+  int xcd_remap;  // 1: workgroups that share an XCD (equal blockIdx % 8) take consecutive tiles
   __device__ __forceinline__ float2 col(int) const { return make_float2(coef[0] * scale, 0.f); }
   __device__ __forceinline__ float pre(int m, int n) const { return weight[(size_t)m * L1 + n]; }
   __device__ __forceinline__ void store(int m, int n, float v, float2 c, float w, int) const {
@@ -769,8 +770,20 @@ __global__ __launch_bounds__(256) void ftm_gemm_bf_kernel(Mat ma, Mat mb, Epi ep
     if (blockIdx.y == 0) bucket_group_body<256>(ga, reinterpret_cast<int*>(smem));
     return;
   }
-  const int k_lo = blockIdx.y * klen;
-  gemm_tile_bf<BM, BN, AKC, Epi>(smem, ma, mb, epi, M, N, k_lo, (k_lo + klen < K) ? k_lo + klen : K, tiles_n, blockIdx.x, blockIdx.y);
+  const int ks = blockIdx.y, k_lo = ks * klen;
+  int tile = blockIdx.x;
+  // (dealing the K slices of the split-K forward to the XCDs instead of its column tiles -- one L2 per map slice -- was
+  // measured at the 224x224 shape and changes nothing: 68.7 vs 69.1 us)
+  if constexpr (is_rmw<Epi>::value) {
+    // Blocks are dealt round-robin over the 8 XCDs (observed, never relied on for results): with this remap the blocks of one
+    // XCD walk a contiguous run of tiles, so the 16 column tiles that share a map tile meet in ONE L2 instead of eight.
+    // Bijective for any grid size (cdna_hip_programming.md, XCD swizzle).
+    if (epi.xcd_remap) {
+      const int nwg = gridDim.x, xcd = tile & 7, q8 = nwg >> 3, r8 = nwg & 7;
+      tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile >> 3);
+    }
+  }
+  gemm_tile_bf<BM, BN, AKC, Epi>(smem, ma, mb, epi, M, N, k_lo, (k_lo + klen < K) ? k_lo + klen : K, tiles_n, tile, ks);
 }
 
 template <int BM>
@@ -1663,9 +1676,10 @@ extern "C" int nnue_ftm_backward_weight_update(const uint8_t* bits, const float*
     s.tiles_m = (direct + 63) / 64; s.tiles_n = (L1 + 63) / 64; s.ksplit = 1; s.klen = (B + kBfK - 1) / kBfK * kBfK;
   }
   NNUE_REQUIRE(s.ksplit == 1, NNUE_E_SHAPE, "nnue_ftm_backward_weight_update: the product must not be split along K");
+  static const int xcd = env_int("NNUE_FTM_XCD_REMAP", 1);  // developer knob
   launch<false, false>(static_cast<hipStream_t>(stream), s, Mat{bits, (unsigned)((size_t)B * P), P, kIntMax, kIntMax},
                        Mat{d_out, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, kIntMax},
-                       BwwSgdEpi{weight, momentum == 0.0f ? nullptr : momentum_rows, coef, L1, lr, momentum, weight_decay, grad_scale, first_step},
+                       BwwSgdEpi{weight, momentum == 0.0f ? nullptr : momentum_rows, coef, L1, lr, momentum, weight_decay, grad_scale, first_step, xcd},
                        direct, L1, B);
   return nnue_launch_status("nnue_ftm_backward_weight_update");
 }

@@ -23,6 +23,10 @@ mkdir -p $R/profiles; for w in c2 c3 c4; do cp $O/kernel_stats_$w.csv $R/profile
 for w in c1 c2 c3 c3k1; do python bench.py --workload $w --steps 300 --warmup 30 > $O/bench_$w.json 2> $O/bench_$w.err || echo "bench $w failed"; done
 python bench.py --workload c4 --steps 100 --warmup 10 > $O/bench_c4.json 2> $O/bench_c4.err || echo "bench c4 failed"
 python bench.py --workload c3 --spread --steps 300 --warmup 30 --no-cpu-baseline > $O/bench_c3_spread.json 2> $O/bench_c3_spread.err
+# one graph launch per step (round-1 form) and the driver's own invocation
+python bench.py --workload c2 --steps 300 --warmup 30 --steps-per-graph 1 --no-cpu-baseline --no-gather-compare > $O/bench_c2_spg1.json 2> $O/bench_c2_spg1.err
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_c2_driver_form.json 2> $O/bench_c2_driver_form.err
+for f in bench_c2_spg1 bench_c2_driver_form; do cut -c1-200 $O/$f.json; echo; done
 for w in c1 c2 c3 c3k1 c4; do cut -c1-220 $O/bench_$w.json; echo; done
 # density sweep: thresholds set over all slots and held (lr 0)
 for w in c2 c4; do for d in 0.01 0.05 0.25 0.9; do S=200; [ $w = c4 ] && S=50; python bench.py --workload $w --density $d --steps $S --warmup 10 --no-cpu-baseline > $O/dens_${w}_$d.json 2> $O/dens_${w}_$d.err || echo "density $w $d failed"; done; done
