@@ -1422,8 +1422,12 @@ extern "C" int nnue_ftm_backward_values(const uint8_t* bits, const float* d_out,
   // tiles, six LDS images (144 KB, one workgroup per CU): 178 us against 153 us for this kernel at the 224x224 shape --
   // with one workgroup per CU nothing overlaps the split with the MFMA phase.  (Round 1's attempt with a rounding split: 145-160.)
   // K = L1 runs along the inner index of both operands: A is zeroed past it, the table rows are clamped to F-1
-  launch<true, true>(st, s, Mat{d_out, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, L1},
-                     Mat{weight, (unsigned)((size_t)F * L1 * 4), L1, F - 1, kIntMax}, ValEpi{bits, d_conv_out, P}, B, P, L1);
+  const Mat ma{d_out, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, L1}, mb{weight, (unsigned)((size_t)F * L1 * 4), L1, F - 1, kIntMax};
+  const ValEpi epi{bits, d_conv_out, P};
+  // (128 x 128 x 32 tiles -- every workgroup stages the same d_out rows beside its table rows, so wider tiles cut the bytes
+  // through the CUs' load path from 3x to 2x the table's -- were measured at the 224x224 shape and lose: 152.0 vs 147.1 us;
+  // 184 registers leave two workgroups per CU instead of four.)
+  launch<true, true>(st, s, ma, mb, epi, B, P, L1);
   return nnue_launch_status("nnue_ftm_backward_values");
 }
 
