@@ -235,12 +235,13 @@ def main():
 
     def run_steps(tr, n):
         """n optimizer steps, step i on input slot i % SLOTS; whole groups of S steps as one graph replay."""
-        i = 0
+        i, last = 0, None
         while S > 1 and i + S <= n:
-            tr.step_many(tuple((i + j) % SLOTS for j in range(S)))
+            last = tr.step_many(tuple((i + j) % SLOTS for j in range(S)))[-1]  # falls back to single steps where it must
             i += S
         for j in range(i, n):
-            tr.step(slot=j % SLOTS)
+            last = tr.step(slot=j % SLOTS)
+        return last  # mean loss of the last step (device scalar)
 
     def set_up(tr):
         for i in range(SLOTS + 1):
@@ -252,14 +253,14 @@ def main():
     run_steps(trainer, args.warmup)
     sync()
     t0 = time.perf_counter()
-    run_steps(trainer, args.steps)
+    last_loss = run_steps(trainer, args.steps)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss_after = float(trainer.loss) if S == 1 or args.steps % S else float(trainer.loss_ring[S - 1])
+    loss_after = float(last_loss) if last_loss is not None else float("nan")
     n_mean, n_max = trainer.active_stats()
     bucket_hist = (torch.bincount(trainer.bucket_plan.bucket.long(), minlength=trainer.K).tolist()
                    if trainer.bucket_plan is not None else None)

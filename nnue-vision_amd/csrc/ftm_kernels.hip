@@ -554,7 +554,8 @@ __device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& m
 // ---- the two products whose A operand is the binary map, on the bf16 matrix unit -----------------------------------
 // out = A W and d_W = A^T d_out multiply a {0,1} matrix -- exact in bf16 -- by an f32 one.  A float splits EXACTLY into
 // three bf16 terms by truncation (hi = top 8 significant bits, mid = top 8 bits of the remainder, lo = what is left: at
-// most 8 bits, so nothing is dropped): x = hi + mid + lo identically.  Every product 1 * term is exact, so three
+// most 8 bits, so nothing is dropped): x = hi + mid + lo identically (for |x| >= 2^-103; below that lo, then mid, is a bf16
+// denormal, which the matrix unit flushes: an absolute error below 2^-126, tests/test_gpu_ftm.py).  Every product 1 * term is exact, so three
 // v_mfma_f32_16x16x32_bf16 (f32 accumulate) over the three planes compute the same sum of the same numbers as the f32
 // MFMA -- in another order, like every other path here -- at 3 x 16 cycles per 32 k against 8 x 32 cycles for
 // v_mfma_f32_16x16x4_f32 (MI355X_MICROARCH.md: the f32-input MFMA runs at 1/16 of the bf16 rate).

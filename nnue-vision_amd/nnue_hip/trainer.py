@@ -714,7 +714,11 @@ class NnueTrainer:
                 torch.cuda.synchronize(self.dev)
                 one_graph = False
         if not one_graph:
-            return torch.stack([self.step(slot=s).clone() for s in slots])
+            if self.loss_ring.numel() < len(slots):
+                self.loss_ring = torch.zeros((len(slots),), dtype=torch.float32, device=self.dev)
+            for i, s in enumerate(slots):
+                self.loss_ring[i].copy_(self.step(slot=s), non_blocking=True)
+            return self.loss_ring[:len(slots)]
         graph, ring = self._g_local[(slots, "many")]
         graph.replay()
         self.steps_done += len(slots)

@@ -366,3 +366,44 @@ def test_table_update_in_the_product_epilogue_equals_the_materialised_path(hip, 
         assert abs(a - b) <= 2e-6 * b and b > 0.5  # the clip is active
     assert_close_grad(runs["1"][1], runs["0"][1], "parameters", rtol=1e-6)
     assert_close_grad(runs["1"][2], runs["0"][2], "momentum", rtol=1e-5)
+
+
+@pytest.mark.parametrize("span", (20, 100, 125))
+def test_bf16_split_is_exact_over_the_exponent_range(hip, span):
+    """The three-way truncation split x = hi + mid + lo is exact, so with ONE active position per sample the bf16-split
+    products must return the operand itself, bit for bit: out[b] = W[p_b] (zero bias) and d_W[p_b] = d_out[b], for
+    magnitudes from 2^-span to 2^span.  Span 125 reaches the edge of the normal range: below |x| = 2^-103 the lo (then the
+    mid) part is a bf16 denormal, which the matrix unit flushes -- what is lost is smaller than the smallest normal
+    float (measured 9e-41), so there the bar is an absolute 2^-126."""
+    b, fps, gh, gw, f, l1 = 24, 64, 32, 32, 65536, 256
+    p = fps * gh * gw
+    lib = hip.load()
+    assert lib.nnue_ftm_uses_bf16(0, b, f, p, l1) == 1 and lib.nnue_ftm_uses_bf16(1, b, f, p, l1) == 1
+    gen = torch.Generator().manual_seed(span)
+
+    def wide(*shape):  # random sign, exponent uniform in [-span, span], full 24-bit mantissa
+        mant = 1.0 + torch.rand(*shape, generator=gen, dtype=torch.float64)
+        e = torch.randint(-span, span + 1, shape, generator=gen).double()
+        sign = torch.randint(0, 2, shape, generator=gen).double() * 2 - 1
+        return (sign * mant * torch.exp2(e)).float()
+
+    pos = torch.randperm(p - 1, generator=gen)[:b]  # distinct positions below the clamp sink
+    conv_out = torch.full((b, p), -1.0)
+    conv_out[torch.arange(b), pos] = 1.0
+    weight, d_out = wide(f, l1), wide(b, l1)
+    fm = hip.ftm_binarize(conv_out.view(b, fps, gh, gw).to(DEV), torch.zeros(fps, device=DEV), f, l1)
+    assert torch.equal(fm.n.cpu(), torch.ones(b, dtype=torch.int32))
+    out = hip.ftm_forward(weight.to(DEV), torch.zeros(l1, device=DEV), fm)
+    d_w, _ = hip.ftm_backward_weight(d_out.to(DEV), fm)
+    if span <= 100:
+        assert torch.equal(out.cpu(), weight[pos]), float((out.cpu() - weight[pos]).abs().max())
+        assert torch.equal(d_w[pos.to(DEV)].cpu(), d_out)
+    else:
+        tiny = 2.0 ** -126
+        assert float((out.cpu().double() - weight[pos].double()).abs().max()) < tiny
+        assert float((d_w[pos.to(DEV)].cpu().double() - d_out.double()).abs().max()) < tiny
+        big = weight[pos].abs() >= 2.0 ** -100
+        assert torch.equal(out.cpu()[big], weight[pos][big])
+    rest = torch.ones(f, dtype=torch.bool)
+    rest[pos] = False
+    assert not bool(d_w[rest.to(DEV)].any())
