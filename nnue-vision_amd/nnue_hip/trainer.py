@@ -682,8 +682,8 @@ class NnueTrainer:
         """``len(slots)`` consecutive optimizer steps on what the named input slots already hold (fill
         ``trainer.inputs[s]`` first; a slot may repeat), replayed as ONE hipGraph: the same kernels in the same order as
         ``step(slot=s)`` for each s, without the gap between two graph launches (measured 5 us at the CIFAR batch-512
-        configuration, 5 % of its step).  Returns the mean loss of every step (device vector, no sync); ``self.loss`` is not
-        written.  Falls back to single steps while the plans are not recorded yet, without graphs, or with an eager
+        configuration, 5 % of its step).  Returns the mean loss of every step (device vector, no sync; a view of a ring
+        the next call overwrites); ``self.loss`` is not written.  Falls back to single steps while the plans are not recorded yet, without graphs, or with an eager
         collective."""
         slots = tuple(int(s) for s in slots)
         if not slots or min(slots) < 0 or max(slots) >= len(self.inputs):
