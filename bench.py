@@ -384,22 +384,23 @@ def main():
             f"{ftp}_forward_grouping": ([("bf16" if uses(0) else "f32", f_fwd)], tbl + mp + act),
             f"{ftp}_forward_l1": ([("bf16" if uses(0) else "f32", f_fwd), ("f32", f_l1)], tbl + mp + act + (L1 // 64) * B * L2 * 4.0),
             f"{ftp}_backward_weight": ([("bf16" if uses(1) else "f32", f_w)], mp + act + tbl),
-            f"{ftp}_backward_values": ([("f32", f_v)], act + F * L1 * 4.0 + mp + B * P * 4.0),
+            f"{ftp}_backward_values": ([("bf16x6" if uses(4) else "f32", f_v)], act + F * L1 * 4.0 + mp + B * P * 4.0),
             f"{ftp}_backward_weight_update": ([("bf16", f_w)], mp + act + 2 * tbl + (2 * tbl if OPT["momentum"] else 0)),
         }
-        bw = [("bf16" if uses(2) else "f32", f_w), ("f32", f_v)] + ([("f32", f_l1)] if getattr(trainer, "ride_dw1", False) else [])
+        bw = [("bf16" if uses(2) else "f32", f_w), ("bf16x6" if uses(5) else "f32", f_v)] + ([("f32", f_l1)] if getattr(trainer, "ride_dw1", False) else [])
         work[f"{ftp}_backward"] = (bw, 2 * mp + act + F * L1 * 4.0 + tbl + B * P * 4.0)
         work[f"{ftp}_backward_bucketed"] = work[f"{ftp}_backward"]
-        PEAK = {"f32": MFMA_F32_PEAK_TFLOPS, "bf16": MFMA_BF16_PEAK_TFLOPS}
+        PEAK = {"f32": MFMA_F32_PEAK_TFLOPS, "bf16": MFMA_BF16_PEAK_TFLOPS, "bf16x6": MFMA_BF16_PEAK_TFLOPS}
+        PASSES = {"f32": 1, "bf16": 3, "bf16x6": 6}  # bf16 MFMAs per logical product: exact split of one operand / six plane products of two
         units, comp_bytes = work[dom]
         useful = sum(f for _, f in units)
-        t_mfma = sum(f * (3.0 if u == "bf16" else 1.0) / (PEAK[u] * 1e12) for u, f in units)  # seconds at the units' peaks
+        t_mfma = sum(f * PASSES[u] / (PEAK[u] * 1e12) for u, f in units)  # seconds at the units' peaks
         t_hbm = comp_bytes / (HBM_PEAK_GBS * 1e9)
         dur = dur_us[dom] * 1e-6
         rp = rocprof_avg_us(dom)
         common = {"kernel": dom, "traffic": (pmc_traffic(dom) or {}).get("bytes"), "traffic_detail": pmc_traffic(dom),
                   "compulsory_bytes": int(comp_bytes), "flops_per_launch": int(useful),
-                  "matrix_work": [{"unit": u, "useful_flops": int(f), "peak_TFLOPs": PEAK[u], "mfma_flops": int(f * (3 if u == "bf16" else 1))}
+                  "matrix_work": [{"unit": u, "useful_flops": int(f), "peak_TFLOPs": PEAK[u], "mfma_flops": int(f * PASSES[u])}
                                   for u, f in units],
                   "ideal_us": {"mfma": round(t_mfma * 1e6, 2), "hbm": round(t_hbm * 1e6, 2)},
                   "avg_launch_us": round(dur_us[dom], 2), "rocprof_avg_us": rp["us"] if rp else None, "rocprof_source": rp["source"] if rp else None,
@@ -419,7 +420,7 @@ def main():
                         **common,
                         "regime": "useful flops of the products in the launch (2 M N K over the whole map) / HIP-event duration, against the "
                                   "peak of the unit each product runs on (f32-input MFMA 157.3 TF; bf16 MFMA 2.5 PF at three MFMAs per "
-                                  "product for the exact split); table %.1f MB" % table_mb}
+                                  "product for the exact split of one operand, six for the plane products of two f32 operands); table %.1f MB" % table_mb}
     else:
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(alg_rate, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(alg_rate / HBM_PEAK_GBS, 4), "traffic": (pmc_traffic(dom) or {}).get("bytes"),

@@ -421,7 +421,9 @@ int nnue_ftm_backward_weight_update(const uint8_t* bits, const float* d_out, int
 
 /* Reporting only: 1 when the product of this shape runs on the bf16 matrix unit (exact three-way split of the f32
  * operand), 0 on the f32 MFMA.  which: 0 forward, 1 stand-alone weight gradient, 2 weight-gradient tiles of the merged
- * backward launch, 3 weight gradient with the update in its epilogue. */
+ * backward launch, 3 weight gradient with the update in its epilogue; 4 stand-alone value gradient, 5 value-gradient tiles
+ * of the merged launch (both operands f32: six bf16 plane products hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi of the
+ * two truncation splits -- what is left out is below 2^-23 of a product). */
 int nnue_ftm_uses_bf16(int which, int B, int F, int P, int L1);
 
 /* nnue_ftm_backward for bucketed layer stacks (declared with the FeatureTransformer entry points above): d_w1 [K][L2][L1],

@@ -764,6 +764,144 @@ __device__ __forceinline__ void gemm_tile_bf(unsigned char* __restrict__ smem, c
   }
 }
 
+// ---- both operands f32 (the value gradient d_out W^T), on the bf16 matrix unit ------------------------------------------
+// Both operands are split into the three truncation planes; the six plane products whose weight is >= 2^-16
+// (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi) are accumulated, smallest first.  Left out: mid lo + lo mid (<= 2^-23 of a
+// product, the size of an f32 rounding) and lo lo (2^-32).  Both operands are contiguous along k in memory, so a thread owns
+// runs of 8 k of one row (two 16-byte loads), splits them in registers and writes one 16-byte chunk per plane; images are
+// [row][64 k] bf16 (128-byte rows, chunk index XOR-swizzled by row / 2 like the f32 kernel's 32-float rows).  K tile 64:
+// six images of a 128 x 64 tile are 72 KB (two workgroups per CU); the first attempt of the round used K tiles of 128 and
+// 144 KB -- one workgroup per CU, nothing overlapped its split with another's MFMA phase, and it lost (178 vs 153 us).
+constexpr int kBf6K = 64;
+template <int BM, int BN>
+constexpr int gemm_bf6_lds_bytes() { return 3 * (BM + BN) * kBf6K * 2; }
+__device__ __forceinline__ int bf6_img(int row, int chunk) { return row * (kBf6K * 2) + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// 8 consecutive k (two float4) -> one 16-byte chunk of 8 bf16 per plane
+__device__ __forceinline__ void split8(const u32x4& v0, const u32x4& v1, u32x4& hi, u32x4& mid, u32x4& lo) {
+  unsigned h[8], m[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const unsigned xb = e < 4 ? v0[e] : v1[e - 4];
+    const float x = __uint_as_float(xb);
+    const unsigned hb = xb & 0xffff0000u;
+    const float r1 = x - __uint_as_float(hb);
+    const unsigned mb_ = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(mb_);
+    h[e] = hb; m[e] = mb_; l[e] = __float_as_uint(r2);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {  // word t: k = 2 t (low half), 2 t + 1 (high half)
+    hi[t] = __builtin_amdgcn_perm(h[2 * t + 1], h[2 * t], 0x07060302u);
+    mid[t] = __builtin_amdgcn_perm(m[2 * t + 1], m[2 * t], 0x07060302u);
+    lo[t] = __builtin_amdgcn_perm(l[2 * t + 1], l[2 * t], 0x07060302u);
+  }
+}
+
+template <int BM, int BN, class Epi>
+__device__ __forceinline__ void gemm_tile_bf6(unsigned char* __restrict__ smem, const Mat& ma, const Mat& mb, const Epi& epi, int M, int N,
+                                              int k_lo, int k_hi, int tiles_n, int tile, int ks) {
+  static_assert((BM == 32 || BM == 64 || BM == 128) && (BN == 64 || BN == 128), "tile shapes");
+  constexpr int TM = BM / 32, TN = BN / 32;
+  constexpr int PA = BM * kBf6K * 2, PB = BN * kBf6K * 2;  // bytes per plane
+  unsigned char* __restrict__ As = smem;
+  unsigned char* __restrict__ Bs = smem + 3 * PA;
+  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ma.p), 0, ma.bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(mb.p), 0, mb.bytes, 0x00020000);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
+  const int m_base = tile_m * BM, n_base = tile_n * BN;
+  const int m0 = (wave >> 1) * (BM / 2), n0 = (wave & 1) * (BN / 2);
+  constexpr int GA = BM * 8 / 256, GB = BN * 8 / 256;  // 8-k runs per thread
+  const bool stream_b = mb.bytes > (64u << 20);        // uniform: a table larger than the caches is read non-temporally
+  u32x4 ra[GA][2], rb[GB][2];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+      const int g = tid + 256 * i, row = g >> 3, k = k0 + (g & 7) * 8;
+      ra[i][0] = mat_load<false>(rsa, ma, m_base + row, k);
+      ra[i][1] = mat_load<false>(rsa, ma, m_base + row, k + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < GB; ++i) {
+      const int g = tid + 256 * i, row = g >> 3, k = k0 + (g & 7) * 8;
+      const int rr = n_base + row < mb.clamp ? n_base + row : mb.clamp;
+      const int off0 = k < mb.inner_k ? (rr * mb.ld + k) * 4 : 0x7ffffff0, off1 = k + 4 < mb.inner_k ? (rr * mb.ld + k + 4) * 4 : 0x7ffffff0;
+      if (stream_b) {
+        rb[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rsb, off0, 0, 2);
+        rb[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rsb, off1, 0, 2);
+      } else {
+        rb[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rsb, off0, 0, 0);
+        rb[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rsb, off1, 0, 0);
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+      const int g = tid + 256 * i, row = g >> 3, c = g & 7;
+      u32x4 hi, mid, lo;
+      split8(ra[i][0], ra[i][1], hi, mid, lo);
+      *reinterpret_cast<u32x4*>(As + bf6_img(row, c)) = hi;
+      *reinterpret_cast<u32x4*>(As + PA + bf6_img(row, c)) = mid;
+      *reinterpret_cast<u32x4*>(As + 2 * PA + bf6_img(row, c)) = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < GB; ++i) {
+      const int g = tid + 256 * i, row = g >> 3, c = g & 7;
+      u32x4 hi, mid, lo;
+      split8(rb[i][0], rb[i][1], hi, mid, lo);
+      *reinterpret_cast<u32x4*>(Bs + bf6_img(row, c)) = hi;
+      *reinterpret_cast<u32x4*>(Bs + PB + bf6_img(row, c)) = mid;
+      *reinterpret_cast<u32x4*>(Bs + 2 * PB + bf6_img(row, c)) = lo;
+    }
+  };
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto contract = [&]() {
+#pragma unroll
+    for (int kb = 0; kb < kBf6K / 32; ++kb) {
+      const int c = kb * 4 + q;  // this lane's 8 k of the 32-k block
+      bf16x8 a[3][TM], b[3][TN];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[pl][i] = *reinterpret_cast<const bf16x8*>(As + pl * PA + bf6_img(m0 + 16 * i + r, c));
+#pragma unroll
+        for (int t = 0; t < TN; ++t) b[pl][t] = *reinterpret_cast<const bf16x8*>(Bs + pl * PB + bf6_img(n0 + 16 * t + r, c));
+      }
+      // smallest terms first (plane 0 = hi, 1 = mid, 2 = lo); consecutive MFMAs go to different accumulators
+      constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int s6 = 0; s6 < 6; ++s6)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int t = 0; t < TN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa[s6]][i], b[pb[s6]][t], acc[i][t], 0, 0, 0);
+    }
+  };
+  fetch(k_lo);
+  for (int k0 = k_lo; k0 < k_hi; k0 += kBf6K) {
+    stage();
+    __syncthreads();
+    if (k0 + kBf6K < k_hi) fetch(k0 + kBf6K);
+    contract();
+    __syncthreads();
+  }
+  store_tile<BM, BN, Epi>(reinterpret_cast<float*>(smem), epi, acc, M, N, m_base, n_base, m0, n0, tile, ks);
+}
+
+template <int BM, int BN, class Epi>
+__global__ __launch_bounds__(256) void ftm_gemm_bf6_kernel(Mat ma, Mat mb, Epi epi, int M, int N, int K, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[gemm_bf6_lds_bytes<BM, BN>()];
+  gemm_tile_bf6<BM, BN, Epi>(smem, ma, mb, epi, M, N, 0, K, tiles_n, blockIdx.x, 0);
+}
+
 template <int BM, int BN, bool AKC, class Epi>
 __global__ __launch_bounds__(256) void ftm_gemm_bf_kernel(Mat ma, Mat mb, Epi epi, int M, int N, int K, int klen, int tiles_n, GroupArgs ga) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[gemm_bf_lds_bytes<BM, BN>()];
@@ -958,18 +1096,19 @@ __global__ __launch_bounds__(256) void ftm_backward_kernel(Mat wa, Mat wb, BwwEp
 
 // The same launch with the weight-gradient tiles on the bf16 matrix unit (gemm_tile_bf, WM x 64 x 128); value-gradient
 // tiles (both operands f32) and the rider keep the f32 MFMA.
-template <int WM, int VM, int VN, int VK>
+template <int WM, int VM, int VN, int VK, bool V6 = false>
 __global__ __launch_bounds__(256) void ftm_backward_bf_kernel(Mat wa, Mat wb, BwwEpi we, int wM, int wN, int wK, int w_tiles_n, int n_w,
                                                               Mat va, Mat vb, ValEpi ve, int vM, int vN, int vK, int v_tiles_n, int n_v,
                                                               CwArgs c, TailRows t) {
-  constexpr int kW = gemm_bf_lds_bytes<WM, 64>(), kV = gemm_lds_floats<VM, VN, VK, true, true>() * 4;
+  constexpr int kW = gemm_bf_lds_bytes<WM, 64>(), kV = V6 ? gemm_bf6_lds_bytes<VM, VN>() : gemm_lds_floats<VM, VN, VK, true, true>() * 4;
   constexpr int kC = gemm_lds_floats<32, 64, 128, false, false>() * 4;
   constexpr int kWV = kW > kV ? kW : kV;
   __shared__ __attribute__((aligned(16))) unsigned char smem_b[kWV > kC ? kWV : kC];
   float* smem = reinterpret_cast<float*>(smem_b);
   const int blk = blockIdx.x;
   if (blk < n_v) {
-    gemm_tile<VM, VN, VK, true, true, ValEpi>(smem, va, vb, ve, vM, vN, 0, vK, v_tiles_n, blk, 0);
+    if constexpr (V6) gemm_tile_bf6<VM, VN, ValEpi>(smem_b, va, vb, ve, vM, vN, 0, vK, v_tiles_n, blk, 0);
+    else gemm_tile<VM, VN, VK, true, true, ValEpi>(smem, va, vb, ve, vM, vN, 0, vK, v_tiles_n, blk, 0);
   } else if (blk < n_v + n_w) {
     gemm_tile_bf<WM, 64, false, BwwEpi>(smem_b, wa, wb, we, wM, wN, 0, wK, w_tiles_n, blk - n_v, 0);
   } else if (blk < n_v + n_w + c.n_c) {
@@ -1410,6 +1549,15 @@ int backward_weight_impl(const uint8_t* bits, const float* sink, const float* d_
 }
 }  // namespace
 
+namespace {
+// the stand-alone value gradient as six bf16 plane products (gemm_tile_bf6): the big-map shape's 128 x 64 tiles
+bool values_bf6(int B, int P, int L1) {
+  static const int bf6 = env_int("NNUE_FTM_VAL_BF6", 1);  // developer knob
+  const Shape s = plan(B, P, L1, true, false);
+  return bf6 && use_bf16() && s.cfg == 2 && s.ksplit == 1 && L1 % 8 == 0;
+}
+}  // namespace
+
 extern "C" int nnue_ftm_backward_values(const uint8_t* bits, const float* d_out, const float* weight, int B, int F, int P, int L1,
                                         float* d_conv_out, nnue_stream_t stream) {
   NNUE_REQUIRE(bits && d_out && weight && d_conv_out, NNUE_E_ARG, "nnue_ftm_backward_values: null pointer");
@@ -1428,6 +1576,11 @@ extern "C" int nnue_ftm_backward_values(const uint8_t* bits, const float* d_out,
   // (128 x 128 x 32 tiles -- every workgroup stages the same d_out rows beside its table rows, so wider tiles cut the bytes
   // through the CUs' load path from 3x to 2x the table's -- were measured at the 224x224 shape and lose: 152.0 vs 147.1 us;
   // 184 registers leave two workgroups per CU instead of four.)
+  if (values_bf6(B, P, L1)) {  // the big-map shape: 128 x 64 tiles, six bf16 plane products (147 -> 117 us at the 224x224 shape)
+    hipLaunchKernelGGL((ftm_gemm_bf6_kernel<128, 64, ValEpi>), dim3((unsigned)(s.tiles_m * s.tiles_n)), dim3(256), 0, st, ma, mb, epi, B, P, L1,
+                       s.tiles_n);
+    return nnue_launch_status("nnue_ftm_backward_values");
+  }
   launch<true, true>(st, s, ma, mb, epi, B, P, L1);
   return nnue_launch_status("nnue_ftm_backward_values");
 }
@@ -1452,6 +1605,15 @@ bool merged_backward_shape(int B, int F, int P, int L1, bool* big) {
   const bool small_pair = sw.cfg == 0 && (sv.cfg == 0 || sv.cfg == 1);
   *big = force_pair == 11 || (force_pair != 1 && small_pair && tiles64 >= 448);
   return !split_launch && (small_pair || *big);
+}
+// value tiles of the merged launch as six bf16 plane products: for the 64 x 64 tiles (C3 shapes: 43.5 vs 46.0 us for the
+// launch); the 32 x 64 tiles of the batch-512 shape are latency-bound per K tile and lose with the 64-deep bf16 tiles (27.2 vs 26.3 us)
+bool merged_values_bf6(int B, int F, int P, int L1) {
+  static const int bf6 = env_int("NNUE_FTM_BWD_BF6", 1);  // developer knob
+  bool big = false;
+  if (!merged_backward_shape(B, F, P, L1, &big) || !merged_bf_wm()) return false;
+  const bool v_small = !big && plan(B, P, L1, true, false).cfg == 0;
+  return bf6 && !v_small && L1 % 8 == 0;
 }
 }  // namespace
 
@@ -1558,9 +1720,14 @@ int ftm_backward_impl(const uint8_t* bits, const float* sink, const float* d_out
   hipLaunchKernelGGL((ftm_backward_kernel<WM, WN, WK, VM, VN, VK>), grid, dim3(256), 0, st, wa, wb, we, direct, L1, B, swr.tiles_n, n_w, va, \
                      vb, ve, B, P, L1, svr.tiles_n, n_v, cw, t)
 #define NNUE_FTM_BWD_BF(WM, VM, VN, VK)                                                                                                  \
-  hipLaunchKernelGGL((ftm_backward_bf_kernel<WM, VM, VN, VK>), grid, dim3(256), 0, st, wa, wb, we, direct, L1, B, swr.tiles_n, n_w, va, vb, ve, \
-                     B, P, L1, svr.tiles_n, n_v, cw, t)
+  do {                                                                                                                                   \
+    if (v6) hipLaunchKernelGGL((ftm_backward_bf_kernel<WM, VM, VN, VK, true>), grid, dim3(256), 0, st, wa, wb, we, direct, L1, B, swr.tiles_n, n_w, va, \
+                               vb, ve, B, P, L1, svr.tiles_n, n_v, cw, t);                                                               \
+    else hipLaunchKernelGGL((ftm_backward_bf_kernel<WM, VM, VN, VK>), grid, dim3(256), 0, st, wa, wb, we, direct, L1, B, swr.tiles_n, n_w, va, vb, \
+                            ve, B, P, L1, svr.tiles_n, n_v, cw, t);                                                                      \
+  } while (0)
   const bool v_small = !big_pair && sv.cfg == 0;
+  const bool v6 = merged_values_bf6(B, F, P, L1);
   if (bf_wm == 64) { if (v_small) NNUE_FTM_BWD_BF(64, 32, 64, 128); else NNUE_FTM_BWD_BF(64, 64, 64, 64); }
   else if (bf_wm == 32) { if (v_small) NNUE_FTM_BWD_BF(32, 32, 64, 128); else NNUE_FTM_BWD_BF(32, 64, 64, 64); }
   else if (big_pair) NNUE_FTM_BWD(64, 64, 64, 64, 64, 64);
@@ -1691,7 +1858,8 @@ extern "C" int nnue_ftm_backward_weight_update(const uint8_t* bits, const float*
 
 // Which matrix unit a product of this shape runs on (the launch policy above, for reporting: bench.py prices a kernel
 // against the peak of the unit it used).  which: 0 forward, 1 stand-alone weight gradient, 2 weight-gradient tiles of the
-// merged backward launch, 3 weight gradient with the update in its epilogue.  1 = bf16-split tiles, 0 = f32 MFMA.
+// merged backward launch, 3 weight gradient with the update in its epilogue, 4 / 5 value gradient (stand-alone / tiles of
+// the merged launch: six plane products).  1 = bf16-split tiles, 0 = f32 MFMA.
 extern "C" int nnue_ftm_uses_bf16(int which, int B, int F, int P, int L1) {
   if (!nnue_ftm_supported(F, P, L1) || !shape_ok(B, F, P, L1)) return 0;
   const int direct = (F - 1 < P) ? F - 1 : P;
@@ -1699,5 +1867,7 @@ extern "C" int nnue_ftm_uses_bf16(int which, int B, int F, int P, int L1) {
   if (which == 0) return plan(B, L1, direct, true, true, true).cfg >= 6;
   if (which == 1) return plan(direct, L1, B, false, false, true).cfg >= 6;
   if (which == 2) { bool big = false; return merged_backward_shape(B, F, P, L1, &big) ? merged_bf_wm() != 0 : plan(direct, L1, B, false, false, true).cfg >= 6; }
+  if (which == 4) return values_bf6(B, P, L1);            // stand-alone value gradient: six bf16 plane products
+  if (which == 5) return merged_values_bf6(B, F, P, L1);  // value tiles of the merged launch
   return 1;
 }
