@@ -769,13 +769,21 @@ __device__ __forceinline__ void gemm_tile_bf(unsigned char* __restrict__ smem, c
 // (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi) are accumulated, smallest first.  Left out: mid lo + lo mid (<= 2^-23 of a
 // product, the size of an f32 rounding) and lo lo (2^-32).  Both operands are contiguous along k in memory, so a thread owns
 // runs of 8 k of one row (two 16-byte loads), splits them in registers and writes one 16-byte chunk per plane; images are
-// [row][64 k] bf16 (128-byte rows, chunk index XOR-swizzled by row / 2 like the f32 kernel's 32-float rows).  K tile 64:
-// six images of a 128 x 64 tile are 72 KB (two workgroups per CU); the first attempt of the round used K tiles of 128 and
-// 144 KB -- one workgroup per CU, nothing overlapped its split with another's MFMA phase, and it lost (178 vs 153 us).
+// [row][KT k] bf16 (KT = 64: 128-byte rows, chunk index XOR-swizzled by row / 2 like the f32 kernel's 32-float rows; KT = 32:
+// 64-byte rows, swizzled by row / 4).  What decides is how many workgroups a CU holds, i.e. how much of one workgroup's split /
+// LDS / MFMA phases another's can hide: the first attempt of the round (K tiles of 128, 144 KB, one workgroup per CU) lost
+// against the f32 MFMA, 178 vs 153 us at the 224x224 shape; K tiles of 64 (72 KB, two per CU) take 115 us, K tiles of 32
+// (36 KB, three per CU: registers) 100 us.  (Splitting d_out -- the same rows for every workgroup, two thirds of a tile's
+// split work -- once per launch into planes in memory instead: 114.8 + 4.6 us for the extra kernel against 117; the split
+// VALU is not what the tile waits for.)
 constexpr int kBf6K = 64;
-template <int BM, int BN>
-constexpr int gemm_bf6_lds_bytes() { return 3 * (BM + BN) * kBf6K * 2; }
-__device__ __forceinline__ int bf6_img(int row, int chunk) { return row * (kBf6K * 2) + ((chunk ^ ((row >> 1) & 7)) << 4); }
+template <int BM, int BN, int KT = kBf6K>
+constexpr int gemm_bf6_lds_bytes() { return 3 * (BM + BN) * KT * 2; }
+// rows of KT bf16 (128 or 64 bytes): two or four rows per 256-byte bank row, chunk index XOR-swizzled accordingly
+template <int KT>
+__device__ __forceinline__ int bf6_img(int row, int chunk) {
+  return row * (KT * 2) + ((chunk ^ (KT == 64 ? (row >> 1) & 7 : (row >> 2) & 3)) << 4);
+}
 
 // 8 consecutive k (two float4) -> one 16-byte chunk of 8 bf16 per plane
 __device__ __forceinline__ void split8(const u32x4& v0, const u32x4& v1, u32x4& hi, u32x4& mid, u32x4& lo) {
@@ -798,12 +806,13 @@ __device__ __forceinline__ void split8(const u32x4& v0, const u32x4& v1, u32x4& 
   }
 }
 
-template <int BM, int BN, class Epi>
+template <int BM, int BN, class Epi, int KT = kBf6K>
 __device__ __forceinline__ void gemm_tile_bf6(unsigned char* __restrict__ smem, const Mat& ma, const Mat& mb, const Epi& epi, int M, int N,
                                               int k_lo, int k_hi, int tiles_n, int tile, int ks) {
   static_assert((BM == 32 || BM == 64 || BM == 128) && (BN == 64 || BN == 128), "tile shapes");
   constexpr int TM = BM / 32, TN = BN / 32;
-  constexpr int PA = BM * kBf6K * 2, PB = BN * kBf6K * 2;  // bytes per plane
+  constexpr int PA = BM * KT * 2, PB = BN * KT * 2;  // bytes per plane
+  constexpr int RUNS = KT / 8;                      // 8-k runs per row of a K tile
   unsigned char* __restrict__ As = smem;
   unsigned char* __restrict__ Bs = smem + 3 * PA;
   const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ma.p), 0, ma.bytes, 0x00020000);
@@ -814,19 +823,20 @@ __device__ __forceinline__ void gemm_tile_bf6(unsigned char* __restrict__ smem, 
   const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
   const int m_base = tile_m * BM, n_base = tile_n * BN;
   const int m0 = (wave >> 1) * (BM / 2), n0 = (wave & 1) * (BN / 2);
-  constexpr int GA = BM * 8 / 256, GB = BN * 8 / 256;  // 8-k runs per thread
+  constexpr int GA = BM * RUNS / 256, GB = BN * RUNS / 256;  // 8-k runs per thread
+  static_assert(GA >= 1 && GB >= 1, "every thread stages at least one run of each operand");
   const bool stream_b = mb.bytes > (64u << 20);        // uniform: a table larger than the caches is read non-temporally
   u32x4 ra[GA][2], rb[GB][2];
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
-      const int g = tid + 256 * i, row = g >> 3, k = k0 + (g & 7) * 8;
+      const int g = tid + 256 * i, row = g / RUNS, k = k0 + (g % RUNS) * 8;
       ra[i][0] = mat_load<false>(rsa, ma, m_base + row, k);
       ra[i][1] = mat_load<false>(rsa, ma, m_base + row, k + 4);
     }
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
-      const int g = tid + 256 * i, row = g >> 3, k = k0 + (g & 7) * 8;
+      const int g = tid + 256 * i, row = g / RUNS, k = k0 + (g % RUNS) * 8;
       const int rr = n_base + row < mb.clamp ? n_base + row : mb.clamp;
       const int off0 = k < mb.inner_k ? (rr * mb.ld + k) * 4 : 0x7ffffff0, off1 = k + 4 < mb.inner_k ? (rr * mb.ld + k + 4) * 4 : 0x7ffffff0;
       if (stream_b) {
@@ -841,21 +851,21 @@ __device__ __forceinline__ void gemm_tile_bf6(unsigned char* __restrict__ smem, 
   auto stage = [&]() {
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
-      const int g = tid + 256 * i, row = g >> 3, c = g & 7;
+      const int g = tid + 256 * i, row = g / RUNS, c = g % RUNS;
       u32x4 hi, mid, lo;
       split8(ra[i][0], ra[i][1], hi, mid, lo);
-      *reinterpret_cast<u32x4*>(As + bf6_img(row, c)) = hi;
-      *reinterpret_cast<u32x4*>(As + PA + bf6_img(row, c)) = mid;
-      *reinterpret_cast<u32x4*>(As + 2 * PA + bf6_img(row, c)) = lo;
+      *reinterpret_cast<u32x4*>(As + bf6_img<KT>(row, c)) = hi;
+      *reinterpret_cast<u32x4*>(As + PA + bf6_img<KT>(row, c)) = mid;
+      *reinterpret_cast<u32x4*>(As + 2 * PA + bf6_img<KT>(row, c)) = lo;
     }
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
-      const int g = tid + 256 * i, row = g >> 3, c = g & 7;
+      const int g = tid + 256 * i, row = g / RUNS, c = g % RUNS;
       u32x4 hi, mid, lo;
       split8(rb[i][0], rb[i][1], hi, mid, lo);
-      *reinterpret_cast<u32x4*>(Bs + bf6_img(row, c)) = hi;
-      *reinterpret_cast<u32x4*>(Bs + PB + bf6_img(row, c)) = mid;
-      *reinterpret_cast<u32x4*>(Bs + 2 * PB + bf6_img(row, c)) = lo;
+      *reinterpret_cast<u32x4*>(Bs + bf6_img<KT>(row, c)) = hi;
+      *reinterpret_cast<u32x4*>(Bs + PB + bf6_img<KT>(row, c)) = mid;
+      *reinterpret_cast<u32x4*>(Bs + 2 * PB + bf6_img<KT>(row, c)) = lo;
     }
   };
   f32x4 acc[TM][TN];
@@ -865,15 +875,15 @@ __device__ __forceinline__ void gemm_tile_bf6(unsigned char* __restrict__ smem, 
     for (int t = 0; t < TN; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   auto contract = [&]() {
 #pragma unroll
-    for (int kb = 0; kb < kBf6K / 32; ++kb) {
+    for (int kb = 0; kb < KT / 32; ++kb) {
       const int c = kb * 4 + q;  // this lane's 8 k of the 32-k block
       bf16x8 a[3][TM], b[3][TN];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[pl][i] = *reinterpret_cast<const bf16x8*>(As + pl * PA + bf6_img(m0 + 16 * i + r, c));
+        for (int i = 0; i < TM; ++i) a[pl][i] = *reinterpret_cast<const bf16x8*>(As + pl * PA + bf6_img<KT>(m0 + 16 * i + r, c));
 #pragma unroll
-        for (int t = 0; t < TN; ++t) b[pl][t] = *reinterpret_cast<const bf16x8*>(Bs + pl * PB + bf6_img(n0 + 16 * t + r, c));
+        for (int t = 0; t < TN; ++t) b[pl][t] = *reinterpret_cast<const bf16x8*>(Bs + pl * PB + bf6_img<KT>(n0 + 16 * t + r, c));
       }
       // smallest terms first (plane 0 = hi, 1 = mid, 2 = lo); consecutive MFMAs go to different accumulators
       constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
@@ -886,20 +896,20 @@ __device__ __forceinline__ void gemm_tile_bf6(unsigned char* __restrict__ smem, 
     }
   };
   fetch(k_lo);
-  for (int k0 = k_lo; k0 < k_hi; k0 += kBf6K) {
+  for (int k0 = k_lo; k0 < k_hi; k0 += KT) {
     stage();
     __syncthreads();
-    if (k0 + kBf6K < k_hi) fetch(k0 + kBf6K);
+    if (k0 + KT < k_hi) fetch(k0 + KT);
     contract();
     __syncthreads();
   }
   store_tile<BM, BN, Epi>(reinterpret_cast<float*>(smem), epi, acc, M, N, m_base, n_base, m0, n0, tile, ks);
 }
 
-template <int BM, int BN, class Epi>
+template <int BM, int BN, class Epi, int KT>
 __global__ __launch_bounds__(256) void ftm_gemm_bf6_kernel(Mat ma, Mat mb, Epi epi, int M, int N, int K, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[gemm_bf6_lds_bytes<BM, BN>()];
-  gemm_tile_bf6<BM, BN, Epi>(smem, ma, mb, epi, M, N, 0, K, tiles_n, blockIdx.x, 0);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[gemm_bf6_lds_bytes<BM, BN, KT>()];
+  gemm_tile_bf6<BM, BN, Epi, KT>(smem, ma, mb, epi, M, N, 0, K, tiles_n, blockIdx.x, 0);
 }
 
 template <int BM, int BN, bool AKC, class Epi>
@@ -1577,8 +1587,12 @@ extern "C" int nnue_ftm_backward_values(const uint8_t* bits, const float* d_out,
   // through the CUs' load path from 3x to 2x the table's -- were measured at the 224x224 shape and lose: 152.0 vs 147.1 us;
   // 184 registers leave two workgroups per CU instead of four.)
   if (values_bf6(B, P, L1)) {  // the big-map shape: 128 x 64 tiles, six bf16 plane products (147 -> 117 us at the 224x224 shape)
-    hipLaunchKernelGGL((ftm_gemm_bf6_kernel<128, 64, ValEpi>), dim3((unsigned)(s.tiles_m * s.tiles_n)), dim3(256), 0, st, ma, mb, epi, B, P, L1,
-                       s.tiles_n);
+    // K tiles of 32: six images of a 128 x 64 tile are 36 KB and 156 registers leave three workgroups per CU -- 100 us against
+    // 115 us with K tiles of 64 (72 KB, two per CU) and 147 us on the f32 MFMA at the 224x224 shape
+    static const int kt = env_int("NNUE_FTM_BF6_KT", 32);  // developer knob
+    const dim3 grid((unsigned)(s.tiles_m * s.tiles_n));
+    if (kt == 64) hipLaunchKernelGGL((ftm_gemm_bf6_kernel<128, 64, ValEpi, 64>), grid, dim3(256), 0, st, ma, mb, epi, B, P, L1, s.tiles_n);
+    else hipLaunchKernelGGL((ftm_gemm_bf6_kernel<128, 64, ValEpi, 32>), grid, dim3(256), 0, st, ma, mb, epi, B, P, L1, s.tiles_n);
     return nnue_launch_status("nnue_ftm_backward_values");
   }
   launch<true, true>(st, s, ma, mb, epi, B, P, L1);
