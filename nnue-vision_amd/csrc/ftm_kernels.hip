@@ -24,6 +24,7 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -764,6 +765,180 @@ __device__ __forceinline__ void gemm_tile_bf(unsigned char* __restrict__ smem, c
   }
 }
 
+// ---- gemm_tile_bf with K tiles of 64 (BM = 128 or 64, BN = 64): half the LDS and fewer live registers, for the kernels
+// whose occupancy is what they wait for -- the two big-table kernels (two workgroups per CU at 80 KB / ~200 registers) and
+// the merged backward launch (its 64 KB were these tiles').  Same arithmetic as gemm_tile_bf; the f32 operand is staged in
+// 4 k x 4 n blocks (four 16-byte loads, 8-byte LDS stores).
+constexpr int kBf64K = 64;
+__device__ __forceinline__ int bf64_img(int row, int chunk) { return row * (kBf64K * 2) + ((chunk ^ ((row >> 1) & 7)) << 4); }
+template <int BM>
+constexpr int gemm_bf64_lds_bytes() { return (BM + 3 * 64) * kBf64K * 2; }
+
+template <int BM, bool AKC, class Epi>
+__device__ __forceinline__ void gemm_tile_bf64(unsigned char* __restrict__ smem, const Mat& ma, const Mat& mb, const Epi& epi, int M, int N,
+                                               int k_lo, int k_hi, int tiles_n, int tile, int ks) {
+  static_assert(BM == 64 || BM == 128, "tile heights");
+  constexpr int BN = 64, KT = kBf64K;
+  constexpr int TM = BM / 32, TN = BN / 32;
+  unsigned char* __restrict__ As = smem;
+  unsigned char* __restrict__ Bs = smem + BM * KT * 2;  // plane p at + p * BN * KT * 2
+  constexpr int PB = BN * KT * 2;
+  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ma.p), 0, ma.bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(mb.p), 0, mb.bytes, 0x00020000);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
+  const int m_base = tile_m * BM, n_base = tile_n * BN;
+  const int m0 = (wave >> 1) * (BM / 2), n0 = (wave & 1) * (BN / 2);
+  // f32 operand: thread = (k block of 4: 16 of them, n block of 4: 16 of them); lanes of a 16-lane group take 4 n x 4 k blocks
+  const int bn4 = (((lane & 3) | ((lane >> 4) << 2))) * 4, bk4 = (((lane >> 2) & 3) | (wave << 2)) * 4;
+  const int b_off = (n_base + bn4) * 4;
+  const bool stream_b = mb.bytes > (64u << 20);  // uniform
+  // A, forward (bytes contiguous along k): 16-byte groups (row, 16 k): 4 per row, two per thread
+  // A, weight gradient (bytes contiguous along m): one 8 k x 4 m block per thread (8 x 32 blocks)
+  auto a_block = [&](int g) {  // as in gemm_tile_bf: 16 consecutive blocks = 4 m blocks x 4 k blocks
+    constexpr int MB = BM / 4;
+    const int grp = g >> 4, l = g & 15;
+    const int groups_m = MB / 4;
+    const int gm = grp % groups_m, gk = grp / groups_m;
+    return ((gk * 4 + (l >> 2)) * MB) + gm * 4 + (l & 3);
+  };
+  constexpr int AGK = BM * 4 / 256;           // forward: 16-byte groups per thread (2 or 1)
+  constexpr int ABLK = (BM / 4) * (KT / 8);   // weight gradient: 8 k x 4 m blocks (256 or 128: the first threads)
+  u32x4 ra[AGK];
+  unsigned rat[8];
+  u32x4 rb[4];
+  auto fetch = [&](int k0) {
+    if constexpr (AKC) {
+#pragma unroll
+      for (int i = 0; i < AGK; ++i) {
+        const int g = tid + 256 * i, row = g >> 2, k = k0 + (g & 3) * 16;
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsa, (m_base + row) * ma.ld + k, 0, 0);
+      }
+    } else {
+      const int g = a_block(tid);
+      const int m4 = (g % (BM / 4)) * 4, k8 = (g / (BM / 4)) * 8;
+      const bool on = tid < ABLK;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rat[j] = __builtin_amdgcn_raw_buffer_load_b32(rsa, on ? (k0 + k8 + j) * ma.ld + m_base + m4 : 0x7ffffff0, 0, 0);
+    }
+    if (stream_b) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsb, (k0 + bk4 + j) * mb.ld * 4 + b_off, 0, 2);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsb, (k0 + bk4 + j) * mb.ld * 4 + b_off, 0, 0);
+    }
+  };
+  auto stage = [&]() {
+    if constexpr (AKC) {
+#pragma unroll
+      for (int i = 0; i < AGK; ++i) {
+        const int g = tid + 256 * i, row = g >> 2, c = (g & 3) * 2;
+        u32x4 lo, hi;
+        unsigned a, b;
+        bytes_to_bf16(ra[i][0], a, b); lo[0] = a; lo[1] = b;
+        bytes_to_bf16(ra[i][1], a, b); lo[2] = a; lo[3] = b;
+        bytes_to_bf16(ra[i][2], a, b); hi[0] = a; hi[1] = b;
+        bytes_to_bf16(ra[i][3], a, b); hi[2] = a; hi[3] = b;
+        *reinterpret_cast<u32x4*>(As + bf64_img(row, c)) = lo;
+        *reinterpret_cast<u32x4*>(As + bf64_img(row, c + 1)) = hi;
+      }
+    } else if (tid < ABLK) {
+      const int g = a_block(tid);
+      const int m4 = (g % (BM / 4)) * 4, c = g / (BM / 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {  // byte e of the eight words = 8 consecutive k of row m4 + e
+        u32x4 v;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const unsigned sel = 0x0c000c00u | (unsigned)e | ((unsigned)(4 + e) << 16);
+          v[t] = __builtin_amdgcn_perm(rat[2 * t + 1], rat[2 * t], sel) * 0x3f80u;
+        }
+        *reinterpret_cast<u32x4*>(As + bf64_img(m4 + e, c)) = v;
+      }
+    }
+    // exact three-way split of the 4 k x 4 n block, packed along k: per n and plane one 8-byte half chunk
+    using u32x2 = __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned;
+    u32x2 pl[3][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      unsigned h[2][4], m[2][4], l[2][4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = __uint_as_float(rb[2 * t + u][e]);
+          const unsigned hb = __float_as_uint(x) & 0xffff0000u;
+          const float r1 = x - __uint_as_float(hb);
+          const unsigned mb_ = __float_as_uint(r1) & 0xffff0000u;
+          const float r2 = r1 - __uint_as_float(mb_);
+          h[u][e] = hb; m[u][e] = mb_; l[u][e] = __float_as_uint(r2);
+        }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pl[0][e][t] = __builtin_amdgcn_perm(h[1][e], h[0][e], 0x07060302u);
+        pl[1][e][t] = __builtin_amdgcn_perm(m[1][e], m[0][e], 0x07060302u);
+        pl[2][e][t] = __builtin_amdgcn_perm(l[1][e], l[0][e], 0x07060302u);
+      }
+    }
+    const int half = (bk4 & 4) ? 8 : 0;
+#pragma unroll
+    for (int pnum = 0; pnum < 3; ++pnum)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) *reinterpret_cast<u32x2*>(Bs + pnum * PB + bf64_img(bn4 + e, bk4 >> 3) + half) = pl[pnum][e];
+  };
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto contract = [&]() {
+#pragma unroll
+    for (int kb = 0; kb < KT / 32; ++kb) {
+      const int c = kb * 4 + q;
+      bf16x8 a[TM], b[3][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(As + bf64_img(m0 + 16 * i + r, c));
+#pragma unroll
+      for (int pnum = 0; pnum < 3; ++pnum)
+#pragma unroll
+        for (int t = 0; t < TN; ++t) b[pnum][t] = *reinterpret_cast<const bf16x8*>(Bs + pnum * PB + bf64_img(n0 + 16 * t + r, c));
+#pragma unroll
+      for (int pnum = 2; pnum >= 0; --pnum)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int t = 0; t < TN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[pnum][t], acc[i][t], 0, 0, 0);
+    }
+  };
+  fetch(k_lo);
+  for (int k0 = k_lo; k0 < k_hi; k0 += KT) {
+    stage();
+    __syncthreads();
+    if (k0 + KT < k_hi) fetch(k0 + KT);
+    contract();
+    __syncthreads();
+  }
+  if constexpr (is_rmw<Epi>::value) rmw_tile<BM, BN, Epi>(reinterpret_cast<float*>(smem), epi, acc, M, N, m_base, n_base, m0, n0);
+  else store_tile<BM, BN, Epi>(reinterpret_cast<float*>(smem), epi, acc, M, N, m_base, n_base, m0, n0, tile, ks);
+}
+
+template <bool AKC, class Epi>
+__global__ __launch_bounds__(256) void ftm_gemm_bf64_kernel(Mat ma, Mat mb, Epi epi, int M, int N, int K, int klen, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[gemm_bf64_lds_bytes<128>()];
+  const int ks = blockIdx.y, k_lo = ks * klen;
+  int tile = blockIdx.x;
+  if constexpr (is_rmw<Epi>::value) {
+    if (epi.xcd_remap) {  // see ftm_gemm_bf_kernel
+      const int nwg = gridDim.x, xcd = tile & 7, q8 = nwg >> 3, r8 = nwg & 7;
+      tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile >> 3);
+    }
+  }
+  gemm_tile_bf64<128, AKC, Epi>(smem, ma, mb, epi, M, N, k_lo, (k_lo + klen < K) ? k_lo + klen : K, tiles_n, tile, ks);
+}
+
 // ---- both operands f32 (the value gradient d_out W^T), on the bf16 matrix unit ------------------------------------------
 // Both operands are split into the three truncation planes; the six plane products whose weight is >= 2^-16
 // (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi) are accumulated, smallest first.  Left out: mid lo + lo mid (<= 2^-23 of a
@@ -1003,8 +1178,10 @@ struct TailRows {
   int col_blocks, zero_slices;  // block grid: col_blocks x (1 + zero_slices)
 };
 
-__device__ __forceinline__ void tail_rows_block(const TailRows& t, int bx, int by) {
-  __shared__ float red[2][16][16];
+// red_mem: 512 floats of the caller's LDS (the merged launches lend their tile buffer: a static array of its own would
+// push them over a third of a CU's LDS)
+__device__ __forceinline__ void tail_rows_block(const TailRows& t, int bx, int by, float* __restrict__ red_mem) {
+  float (*red)[16][16] = reinterpret_cast<float (*)[16][16]>(red_mem);
   const float* __restrict__ d_out = t.d_out;
   const float* __restrict__ sink = t.sink;
   float* __restrict__ d_weight = t.d_weight;
@@ -1055,7 +1232,10 @@ __device__ __forceinline__ void tail_rows_block(const TailRows& t, int bx, int b
   }
 }
 
-__global__ __launch_bounds__(256) void ftm_tail_rows_kernel(TailRows t) { tail_rows_block(t, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void ftm_tail_rows_kernel(TailRows t) {
+  __shared__ float red[512];
+  tail_rows_block(t, blockIdx.x, blockIdx.y, red);
+}
 
 // Weight gradient, value gradient and the tail rows in ONE launch: they are independent (all three read d_out), so
 // their workgroups share the chip instead of queueing behind two kernel boundaries.  Blocks [0, n_v) are value-gradient
@@ -1100,17 +1280,17 @@ __global__ __launch_bounds__(256) void ftm_backward_kernel(Mat wa, Mat wb, BwwEp
     }
   } else {
     const int i = blk - n_w - n_v - c.n_c;
-    tail_rows_block(t, i % t.col_blocks, i / t.col_blocks);
+    tail_rows_block(t, i % t.col_blocks, i / t.col_blocks, smem);
   }
 }
 
 // The same launch with the weight-gradient tiles on the bf16 matrix unit (gemm_tile_bf, WM x 64 x 128); value-gradient
 // tiles (both operands f32) and the rider keep the f32 MFMA.
-template <int WM, int VM, int VN, int VK, bool V6 = false>
+template <int WM, int VM, int VN, int VK, bool V6 = false, bool W64 = false>
 __global__ __launch_bounds__(256) void ftm_backward_bf_kernel(Mat wa, Mat wb, BwwEpi we, int wM, int wN, int wK, int w_tiles_n, int n_w,
                                                               Mat va, Mat vb, ValEpi ve, int vM, int vN, int vK, int v_tiles_n, int n_v,
                                                               CwArgs c, TailRows t) {
-  constexpr int kW = gemm_bf_lds_bytes<WM, 64>(), kV = V6 ? gemm_bf6_lds_bytes<VM, VN>() : gemm_lds_floats<VM, VN, VK, true, true>() * 4;
+  constexpr int kW = W64 ? gemm_bf64_lds_bytes<WM>() : gemm_bf_lds_bytes<WM, 64>(), kV = V6 ? gemm_bf6_lds_bytes<VM, VN>() : gemm_lds_floats<VM, VN, VK, true, true>() * 4;
   constexpr int kC = gemm_lds_floats<32, 64, 128, false, false>() * 4;
   constexpr int kWV = kW > kV ? kW : kV;
   __shared__ __attribute__((aligned(16))) unsigned char smem_b[kWV > kC ? kWV : kC];
@@ -1120,7 +1300,8 @@ __global__ __launch_bounds__(256) void ftm_backward_bf_kernel(Mat wa, Mat wb, Bw
     if constexpr (V6) gemm_tile_bf6<VM, VN, ValEpi>(smem_b, va, vb, ve, vM, vN, 0, vK, v_tiles_n, blk, 0);
     else gemm_tile<VM, VN, VK, true, true, ValEpi>(smem, va, vb, ve, vM, vN, 0, vK, v_tiles_n, blk, 0);
   } else if (blk < n_v + n_w) {
-    gemm_tile_bf<WM, 64, false, BwwEpi>(smem_b, wa, wb, we, wM, wN, 0, wK, w_tiles_n, blk - n_v, 0);
+    if constexpr (W64) gemm_tile_bf64<WM, false, BwwEpi>(smem_b, wa, wb, we, wM, wN, 0, wK, w_tiles_n, blk - n_v, 0);
+    else gemm_tile_bf<WM, 64, false, BwwEpi>(smem_b, wa, wb, we, wM, wN, 0, wK, w_tiles_n, blk - n_v, 0);
   } else if (blk < n_v + n_w + c.n_c) {
     const int t2 = blk - n_v - n_w;
     if (c.seg) {
@@ -1137,7 +1318,7 @@ __global__ __launch_bounds__(256) void ftm_backward_bf_kernel(Mat wa, Mat wb, Bw
     }
   } else {
     const int i = blk - n_w - n_v - c.n_c;
-    tail_rows_block(t, i % t.col_blocks, i / t.col_blocks);
+    tail_rows_block(t, i % t.col_blocks, i / t.col_blocks, smem);
   }
 }
 
@@ -1426,8 +1607,14 @@ void launch(hipStream_t st, const Shape& s, Mat ma, Mat mb, Epi epi, int M, int 
       if constexpr (!BKC && Epi::kAU8) {  // bf16-split tiles: the map times an f32 operand that is contiguous along its rows
 #define NNUE_FTM_LAUNCH_BF(BM) \
   hipLaunchKernelGGL((ftm_gemm_bf_kernel<BM, 64, AKC, Epi>), grid, dim3(256), 0, st, ma, mb, epi, M, N, K, s.klen, s.tiles_n, ga)
+        // 128-row tiles of the big-table kernels (split-K forward, update in the epilogue) with K tiles of 64: 40 KB and
+        // 124 / 152 registers instead of 80 KB and ~190 / 200 -- four / three workgroups per CU instead of two: forward 67.5 -> 64 us,
+        // update 192.5 -> 184 us at the 224x224 shape (A/B in one run)
+        static const int kt64 = env_int("NNUE_FTM_BF_KT64", 1);  // developer knob
         if (s.cfg == 6) NNUE_FTM_LAUNCH_BF(32);
         else if (s.cfg == 7) NNUE_FTM_LAUNCH_BF(64);
+        else if (kt64 && !ga.n && (std::is_same<Epi, FwdEpi>::value || is_rmw<Epi>::value))
+          hipLaunchKernelGGL((ftm_gemm_bf64_kernel<AKC, Epi>), grid, dim3(256), 0, st, ma, mb, epi, M, N, K, s.klen, s.tiles_n);
         else NNUE_FTM_LAUNCH_BF(128);
 #undef NNUE_FTM_LAUNCH_BF
       }
@@ -1735,13 +1922,20 @@ int ftm_backward_impl(const uint8_t* bits, const float* sink, const float* d_out
                      vb, ve, B, P, L1, svr.tiles_n, n_v, cw, t)
 #define NNUE_FTM_BWD_BF(WM, VM, VN, VK)                                                                                                  \
   do {                                                                                                                                   \
-    if (v6) hipLaunchKernelGGL((ftm_backward_bf_kernel<WM, VM, VN, VK, true>), grid, dim3(256), 0, st, wa, wb, we, direct, L1, B, swr.tiles_n, n_w, va, \
+    if (w64 && WM == 64 && !v6) hipLaunchKernelGGL((ftm_backward_bf_kernel<64, VM, VN, VK, false, true>), grid, dim3(256), 0, st, wa, wb, we, direct, L1, B, \
+                               swr.tiles_n, n_w, va, vb, ve, B, P, L1, svr.tiles_n, n_v, cw, t);                                        \
+    else if (w64 && WM == 64) hipLaunchKernelGGL((ftm_backward_bf_kernel<64, VM, VN, VK, true, true>), grid, dim3(256), 0, st, wa, wb, we, direct, L1, B, \
+                               swr.tiles_n, n_w, va, vb, ve, B, P, L1, svr.tiles_n, n_v, cw, t);                                        \
+    else if (v6) hipLaunchKernelGGL((ftm_backward_bf_kernel<WM, VM, VN, VK, true>), grid, dim3(256), 0, st, wa, wb, we, direct, L1, B, swr.tiles_n, n_w, va, \
                                vb, ve, B, P, L1, svr.tiles_n, n_v, cw, t);                                                               \
     else hipLaunchKernelGGL((ftm_backward_bf_kernel<WM, VM, VN, VK>), grid, dim3(256), 0, st, wa, wb, we, direct, L1, B, swr.tiles_n, n_w, va, vb, \
                             ve, B, P, L1, svr.tiles_n, n_v, cw, t);                                                                      \
   } while (0)
   const bool v_small = !big_pair && sv.cfg == 0;
   const bool v6 = merged_values_bf6(B, F, P, L1);
+  // weight tiles with K tiles of 64 (gemm_tile_bf64): the launch's LDS drops from 64 KB to the rider's 52 KB -- three
+  // workgroups per CU instead of two (the 168 registers allow exactly that): 43.5 -> 37.7 us at the C3 shapes, 26.2 -> 25.1 us at C2
+  static const int w64 = env_int("NNUE_FTM_BWD_W64", 1);  // developer knob
   if (bf_wm == 64) { if (v_small) NNUE_FTM_BWD_BF(64, 32, 64, 128); else NNUE_FTM_BWD_BF(64, 64, 64, 64); }
   else if (bf_wm == 32) { if (v_small) NNUE_FTM_BWD_BF(32, 32, 64, 128); else NNUE_FTM_BWD_BF(32, 64, 64, 64); }
   else if (big_pair) NNUE_FTM_BWD(64, 64, 64, 64, 64, 64);
