@@ -375,7 +375,8 @@ struct is_rmw<Epi, decltype((void)Epi::kRmw)> { static constexpr bool value = Ep
 // through LDS and every thread then owns whole float4 runs of a row: all of the tile's parameter and momentum loads are
 // issued before the first result is combined (64 KB in flight per workgroup at 128 x 64).
 // (Requesting the tile's parameters and momentum before the K loop instead -- 64 more live registers -- was measured and
-// loses: 234 vs 200 us at the 224x224 shape; two workgroups per CU already overlap one's epilogue with the other's product.)
+// loses: 234 vs 200 us at the 224x224 shape with the 128-deep tiles, 191-202 vs 188 us with the 64-deep ones (228 registers);
+// 64-row tiles, whose 160 / 108 registers allow three / four workgroups per CU with early / late loads: 197 / 200-204 vs 188 us.)
 template <int BM, int BN, class Epi>
 __device__ __forceinline__ void rmw_tile(float* __restrict__ smem, const Epi& epi, const f32x4 (&acc)[BM / 32][BN / 32], int M, int N,
                                          int m_base, int n_base, int m0, int n0) {
