@@ -410,3 +410,56 @@ def test_bf16_split_is_exact_over_the_exponent_range(hip, span):
     rest = torch.ones(f, dtype=torch.bool)
     rest[pos] = False
     assert not bool(d_w[rest.to(DEV)].any())
+
+
+def test_random_big_map_shapes_sweep(hip):
+    """Six random shapes with maps of thousands to tens of thousands of positions (ragged batches up to 300, odd widths):
+    the shapes that take the bf16-split tiles of either depth, the six-plane-product value gradient, the i8 Gram product
+    and the update in the product's epilogue -- each against the float64 restatement."""
+    rng = torch.Generator().manual_seed(7)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng))  # noqa: E731
+    done = 0
+    while done < 6:
+        b, fps, gh, gw = ri(1, 300), ri(8, 64), ri(12, 32), ri(12, 32)
+        p = fps * gh * gw
+        if p % 4 or p < 4096:
+            continue
+        f = max(2, p + ri(-p // 4, p // 8))
+        l1 = 4 * ri(8, 96)
+        tag = (b, fps, gh, gw, f, l1)
+        conv_out = torch.randn(b, fps, gh, gw, generator=rng)
+        thr = torch.randn(fps, generator=rng) * 0.3
+        weight, bias = torch.randn(f, l1, generator=rng) * 0.1, torch.randn(l1, generator=rng)
+        d_out = torch.randn(b, l1, generator=rng) / b + 0.2 / b
+        ref_out, ref_dw, ref_db, ref_dval, ref_n, ref_sink = dense_reference(conv_out, thr, weight, bias, d_out)
+        g = lambda t: t.to(DEV)  # noqa: E731
+        fm = hip.ftm_binarize(g(conv_out), g(thr), f, l1)
+        assert torch.equal(fm.n.cpu(), ref_n) and torch.equal(fm.sink.cpu(), ref_sink), tag
+        assert_close_grad(hip.ftm_forward(g(weight), g(bias), fm), ref_out, f"out {tag}", rtol=1e-5)
+        d_w, d_b = hip.ftm_backward_weight(g(d_out), fm)
+        assert_close_grad(d_w, ref_dw, f"d_weight {tag}", rtol=2e-5)
+        assert_close_grad(d_b, ref_db, f"d_bias {tag}", rtol=2e-5)
+        d_v = hip.ftm_backward_values(g(d_out), g(weight), fm)
+        assert_close_grad(d_v.view(conv_out.shape), ref_dval, f"d_conv_out {tag}", rtol=2e-5)
+        active = (conv_out > thr.view(1, -1, 1, 1)).reshape(b, -1)
+        assert not bool(d_v.view(b, -1)[~active.to(DEV)].any()), tag
+        # Gram norm of the rows the map reaches, and the update in the product's epilogue against the float64 update
+        direct = min(f - 1, p)
+        gram = torch.full((hip.ftm_gram_scratch(fm),), float("nan"), device=DEV)
+        part = torch.empty(int(hip.load().nnue_ftm_gram_sq_count(b, l1)), device=DEV)
+        hip.ftm_gram_sqnorm(fm, g(d_out), gram, part)
+        ref_sq = float((ref_dw[:direct] ** 2).sum())
+        assert abs(float(part.double().sum()) - ref_sq) <= 2e-6 * ref_sq, tag
+        a = active[:, :direct].double()
+        assert torch.equal(gram[:b * b].view(b, b).cpu().double(), a @ a.t()), tag
+        w_dev, m_dev = g(weight).clone(), (torch.randn(f, l1, generator=rng) * 0.01).to(DEV)
+        mom0 = m_dev.cpu().double()
+        coef = torch.tensor(0.37, device=DEV)
+        lr, mu, wd, gs = 0.05, 0.9, 1e-3, 1.7
+        hip.ftm_backward_weight_update(g(d_out), fm, w_dev, m_dev, coef, lr, mu, wd, gs, False)
+        gg = 0.37 * gs * ref_dw[:direct] + wd * weight[:direct].double()
+        mm = mu * mom0[:direct] + gg
+        assert_close_grad(m_dev[:direct], mm, f"momentum rows {tag}", rtol=2e-5)
+        assert_close_grad(w_dev[:direct], weight[:direct].double() - lr * mm, f"updated rows {tag}", rtol=1e-6)
+        assert torch.equal(w_dev[direct:].cpu(), weight[direct:]) and torch.equal(m_dev[direct:].cpu().double(), mom0[direct:]), tag
+        done += 1
