@@ -54,103 +54,19 @@ __global__ __launch_bounds__(256) void conv3x3_forward_kernel(const float* __res
   }
 }
 
-// Conv forward + StraightThroughBinary.forward as the float {0,1} map + per-sample counts in one launch (the
-// front of the MFMA FeatureTransformer path): same fmaf chain as conv3x3_forward_kernel, so conv_out is bitwise the
-// same; bits[b][c*G+hw] = conv_out > thr[c] (one byte); n[b] / sink[b] as nnue_ftm_binarize.  grid (B, slices): a workgroup
-// walks positions hw = y*T + tid, y*T + tid + slices*T, ... of one sample; with one slice per sample the counts are
-// plain stores, otherwise integer-valued atomics into host-zeroed counters (exact in any order).
+// Conv forward + StraightThroughBinary.forward as the byte {0,1} map + per-sample counts in one launch (the front of the
+// MFMA FeatureTransformer path): conv_binarize.h.  grid (B, slices).
+#include "conv_binarize.h"
+
+template <bool kFullUnroll>
 __global__ __launch_bounds__(256) void conv_binarize_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                             const float* __restrict__ thr, float* __restrict__ out,
                                                             uint8_t* __restrict__ bits, int* __restrict__ n,
                                                             float* __restrict__ sink, int H, int W, int fps, int stride,
                                                             int Gh, int Gw, int F, int slices) {
-  // weights transposed to [27][fpad] (fpad = fps rounded up to 8, pad columns zero): the eight channels of a register
-  // pass are two ds_read_b128 per patch term instead of eight ds_read_b32 -- the kernel was LDS-issue bound (1728 reads
-  // per thread at 64 channels); thr [fpad] behind them
   extern __shared__ __attribute__((aligned(16))) float w_lds[];
-  __shared__ int cnt_s[4], sink_s[4];
-  const int fpad = (fps + 7) & ~7;
-  float* thr_lds = w_lds + 27 * fpad;
-  const int G = Gh * Gw;
-  const int b = blockIdx.x;
-  // the first position's patch is requested before the weights are staged: a launch starts with cold caches, and the
-  // two first-touch latencies (weights, pixels) would otherwise run one after the other
-  float patch[27];
-  auto load_patch = [&](int hw) {
-    const int h = hw / Gw, x = hw - h * Gw;
-#pragma unroll
-    for (int ci = 0; ci < 3; ++ci)
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int iy = h * stride + kh - 1, ix = x * stride + kw - 1;
-          const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
-          patch[ci * 9 + kh * 3 + kw] = in ? img[(((size_t)b * 3 + ci) * H + iy) * W + ix] : 0.0f;
-        }
-  };
-  const int hw0 = blockIdx.y * blockDim.x + threadIdx.x;
-  if (hw0 < G) load_patch(hw0);
-  for (int i = threadIdx.x; i < 27 * fpad; i += blockDim.x) {
-    const int q = i / fpad, c = i - q * fpad;
-    w_lds[i] = c < fps ? w[c * 27 + q] : 0.0f;
-  }
-  for (int i = threadIdx.x; i < fpad; i += blockDim.x) thr_lds[i] = i < fps ? thr[i] : 0.0f;
-  __syncthreads();
-  int cnt = 0, snk = 0;
-  for (int hw = hw0; hw < G; hw += blockDim.x * slices) {
-    if (hw != hw0) load_patch(hw);
-    for (int c0 = 0; c0 < fps; c0 += kConvChunk) {
-      float acc[kConvChunk];
-#pragma unroll
-      for (int u = 0; u < kConvChunk; ++u) acc[u] = 0.0f;
-      static_assert(kConvChunk == 8, "two float4 per patch term");
-#pragma unroll
-      for (int q = 0; q < 27; ++q) {
-        const float4 wa = *reinterpret_cast<const float4*>(&w_lds[q * fpad + c0]);
-        const float4 wb = *reinterpret_cast<const float4*>(&w_lds[q * fpad + c0 + 4]);
-        acc[0] = fmaf(patch[q], wa.x, acc[0]); acc[1] = fmaf(patch[q], wa.y, acc[1]);
-        acc[2] = fmaf(patch[q], wa.z, acc[2]); acc[3] = fmaf(patch[q], wa.w, acc[3]);
-        acc[4] = fmaf(patch[q], wb.x, acc[4]); acc[5] = fmaf(patch[q], wb.y, acc[5]);
-        acc[6] = fmaf(patch[q], wb.z, acc[6]); acc[7] = fmaf(patch[q], wb.w, acc[7]);
-      }
-#pragma unroll
-      for (int u = 0; u < kConvChunk; ++u)
-        if (c0 + u < fps) {
-          const int p = (c0 + u) * G + hw;
-          const size_t o = (size_t)b * fps * G + p;
-          const bool on = acc[u] > thr_lds[c0 + u];
-          out[o] = acc[u];
-          bits[o] = on ? 1 : 0;
-          cnt += on;
-          snk += on && p >= F - 1;
-        }
-    }
-  }
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) {
-    cnt += __shfl_xor(cnt, s);
-    snk += __shfl_xor(snk, s);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    cnt_s[threadIdx.x >> 6] = cnt;
-    sink_s[threadIdx.x >> 6] = snk;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int total = 0, st = 0;
-    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) {
-      total += cnt_s[i];
-      st += sink_s[i];
-    }
-    if (slices == 1) {
-      n[b] = total;
-      sink[b] = (float)st;
-    } else {
-      atomicAdd(&n[b], total);
-      if (st) atomicAdd(&sink[b], (float)st);
-    }
-  }
+  ConvParamsPlain prm{w, thr};
+  conv_binarize_body<kFullUnroll>(img, prm, out, bits, n, sink, H, W, fps, stride, Gh, Gw, F, slices, (int)blockIdx.x, (int)blockIdx.y, w_lds, [] {});
 }
 
 // ------------------------------------------------------------------ binarise + compact
@@ -559,8 +475,11 @@ extern "C" int nnue_ftm_conv_binarize(const float* images, const float* weight, 
   if (slices > (int)(G / threads)) slices = (int)(G / threads);
   slices = slices < 1 ? 1 : (slices > 16 ? 16 : slices);
   if (slices > 1) nnue_zero_counters(n, sink, B, s);  // a kernel, not a memset node (common.h)
-  hipLaunchKernelGGL(conv_binarize_kernel, dim3(B, slices), dim3(threads), (size_t)(((fps + 7) & ~7) * 28) * sizeof(float), s, images, weight, thr, conv_out, bits, n,
-                     sink, H, W, fps, stride, Gh, Gw, F, slices);
+  const size_t lds = (size_t)(((fps + 7) & ~7) * 28) * sizeof(float);
+  if (fps <= 16) hipLaunchKernelGGL(conv_binarize_kernel<true>, dim3(B, slices), dim3(threads), lds, s, images, weight, thr, conv_out, bits, n, sink, H, W, fps,
+                                    stride, Gh, Gw, F, slices);
+  else hipLaunchKernelGGL(conv_binarize_kernel<false>, dim3(B, slices), dim3(threads), lds, s, images, weight, thr, conv_out, bits, n, sink, H, W, fps, stride,
+                          Gh, Gw, F, slices);
   return nnue_launch_status("nnue_ftm_conv_binarize");
 }
 
