@@ -949,7 +949,7 @@ __global__ __launch_bounds__(256) void ftm_gemm_bf64_kernel(Mat ma, Mat mb, Epi 
 // 64-byte rows, swizzled by row / 4).  What decides is how many workgroups a CU holds, i.e. how much of one workgroup's split /
 // LDS / MFMA phases another's can hide: the first attempt of the round (K tiles of 128, 144 KB, one workgroup per CU) lost
 // against the f32 MFMA, 178 vs 153 us at the 224x224 shape; K tiles of 64 (72 KB, two per CU) take 115 us, K tiles of 32
-// (36 KB, three per CU: registers) 100 us.  (Splitting d_out -- the same rows for every workgroup, two thirds of a tile's
+// (36 KB and 120 registers: four per CU) 100 us.  (Splitting d_out -- the same rows for every workgroup, two thirds of a tile's
 // split work -- once per launch into planes in memory instead: 114.8 + 4.6 us for the extra kernel against 117; the split
 // VALU is not what the tile waits for.)
 constexpr int kBf6K = 64;
@@ -1775,7 +1775,7 @@ extern "C" int nnue_ftm_backward_values(const uint8_t* bits, const float* d_out,
   // through the CUs' load path from 3x to 2x the table's -- were measured at the 224x224 shape and lose: 152.0 vs 147.1 us;
   // 184 registers leave two workgroups per CU instead of four.)
   if (values_bf6(B, P, L1)) {  // the big-map shape: 128 x 64 tiles, six bf16 plane products (147 -> 117 us at the 224x224 shape)
-    // K tiles of 32: six images of a 128 x 64 tile are 36 KB and 156 registers leave three workgroups per CU -- 100 us against
+    // K tiles of 32: six images of a 128 x 64 tile are 36 KB and 120 registers -- four workgroups per CU -- 100 us against
     // 115 us with K tiles of 64 (72 KB, two per CU) and 147 us on the f32 MFMA at the 224x224 shape
     static const int kt = env_int("NNUE_FTM_BF6_KT", 32);  // developer knob
     const dim3 grid((unsigned)(s.tiles_m * s.tiles_n));
