@@ -3,6 +3,8 @@
 // Both are small streaming kernels; sums are staged so results are bitwise reproducible.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -249,6 +251,78 @@ __global__ __launch_bounds__(256) void sgd_apply_kernel(float* __restrict__ p, c
   }
 }
 
+// The same update with 16-byte accesses for buffers that are launch-sized (count, the hole and the pointers multiples of 4 /
+// 16 bytes): one float4 per thread and pass, the first two passes requested before the norm is re-derived.  (The scalar kernel
+// stays for big buffers: with 16-byte accesses it streamed 1.34 GB slower, 225-257 vs 211 us.)
+__global__ __launch_bounds__(256) void sgd_apply_vec_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                            int64_t count, float lr, float momentum, float wd, float max_norm, float scale,
+                                                            int first_step, const float* __restrict__ partial, int nparts,
+                                                            float* __restrict__ norm_out, const float* __restrict__ ext_partial, int ext_count,
+                                                            float* __restrict__ coef_out, int64_t skip_lo, int64_t skip_hi) {
+  __shared__ double red[4];
+  __shared__ float coef_s;
+  constexpr int kPre = 2;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t hole4 = (skip_hi - skip_lo) >> 2, lo4 = skip_lo >> 2, live4 = (count >> 2) - hole4;
+  const int64_t j0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const float4* __restrict__ p4 = reinterpret_cast<const float4*>(p);
+  const float4* __restrict__ g4 = reinterpret_cast<const float4*>(g);
+  const float4* __restrict__ m4 = reinterpret_cast<const float4*>(m);
+  float4 pw[kPre], pg[kPre], pm[kPre];
+#pragma unroll
+  for (int u = 0; u < kPre; ++u) {
+    const int64_t j = j0 + u * stride < live4 ? j0 + u * stride : 0;
+    const int64_t i = j < lo4 ? j : j + hole4;
+    pw[u] = p4[i];
+    pg[u] = g4[i];
+    pm[u] = (m && !first_step) ? m4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float clip = 1.0f;
+  if (max_norm > 0.0f || norm_out || coef_out) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += (double)partial[i];
+    if (ext_partial) {
+      const double s2 = (double)scale * (double)scale;
+      for (int i = threadIdx.x; i < ext_count; i += 256) acc += (double)ext_partial[i] * s2;
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float norm = (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
+      if (norm_out && blockIdx.x == 0) *norm_out = norm;
+      coef_s = max_norm > 0.0f ? fminf(max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+      if (coef_out && blockIdx.x == 0) *coef_out = coef_s;
+    }
+    __syncthreads();
+    clip = coef_s;
+  }
+  const float gs = clip * scale;
+  auto one = [&](float w, float gv, float mv, float& m_new) {  // the arithmetic of sgd_apply_kernel, element by element
+    float gi = fmaf(wd, w, gv * gs);
+    if (m) gi = first_step ? gi : fmaf(momentum, mv, gi);
+    m_new = gi;
+    return w - lr * gi;
+  };
+  auto apply = [&](int64_t i, const float4& w, const float4& gv, const float4& mv) {
+    float4 mn, wn;
+    wn.x = one(w.x, gv.x, mv.x, mn.x); wn.y = one(w.y, gv.y, mv.y, mn.y);
+    wn.z = one(w.z, gv.z, mv.z, mn.z); wn.w = one(w.w, gv.w, mv.w, mn.w);
+    if (m) reinterpret_cast<float4*>(m)[i] = mn;
+    reinterpret_cast<float4*>(p)[i] = wn;
+  };
+#pragma unroll
+  for (int u = 0; u < kPre; ++u) {
+    const int64_t j = j0 + u * stride;
+    if (j < live4) apply(j < lo4 ? j : j + hole4, pw[u], pg[u], pm[u]);
+  }
+  for (int64_t j = j0 + kPre * stride; j < live4; j += stride) {
+    const int64_t i = j < lo4 ? j : j + hole4;
+    apply(i, p4[i], g4[i], (m && !first_step) ? m4[i] : make_float4(0.f, 0.f, 0.f, 0.f));
+  }
+}
+
 // Adam (torch.optim.Adam defaults: L2 weight decay folded into the gradient, bias-corrected moments, no
 // amsgrad).  The step number lives in device memory (step_counter[0], incremented here by the norm kernel's
 // first thread) so that the launch has no changing host argument and can be replayed from a hipGraph.
@@ -396,9 +470,20 @@ extern "C" int nnue_sgd_step(float* params, float* grads, float* momentum_buf, i
   int blocks = (int)((live + 1023) / 1024);
   blocks = blocks < 1 ? 1 : blocks;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(sgd_apply_kernel, dim3(blocks), dim3(256), 0, s, params, grads, momentum == 0.0f ? nullptr : momentum_buf,
-                     count, lr, momentum, weight_decay, max_norm, grad_scale, first_step, partial, nparts, norm_out, ext_partial, ext_count,
-                     coef_out, ext_applied_elsewhere ? ext_lo : (int64_t)0, ext_applied_elsewhere ? ext_hi : (int64_t)0);
+  const int64_t skip_lo = ext_applied_elsewhere ? ext_lo : 0, skip_hi = ext_applied_elsewhere ? ext_hi : 0;
+  float* mom = momentum == 0.0f ? nullptr : momentum_buf;
+  static const char* novec = std::getenv("NNUE_SGD_SCALAR");
+  const bool vec = !(novec && novec[0] == '1') && live <= (16ll << 20) && count % 4 == 0 && skip_lo % 4 == 0 && skip_hi % 4 == 0 &&
+                   nnue_aligned16(params) && nnue_aligned16(grads) && (!mom || nnue_aligned16(mom));
+  if (vec) {
+    int vb = (int)((live / 4 + 511) / 512);  // two float4 passes per thread
+    vb = vb < 1 ? 1 : (vb > 2048 ? 2048 : vb);
+    hipLaunchKernelGGL(sgd_apply_vec_kernel, dim3(vb), dim3(256), 0, s, params, grads, mom, count, lr, momentum, weight_decay, max_norm, grad_scale,
+                       first_step, partial, nparts, norm_out, ext_partial, ext_count, coef_out, skip_lo, skip_hi);
+    return nnue_launch_status("nnue_sgd_step");
+  }
+  hipLaunchKernelGGL(sgd_apply_kernel, dim3(blocks), dim3(256), 0, s, params, grads, mom, count, lr, momentum, weight_decay, max_norm, grad_scale,
+                     first_step, partial, nparts, norm_out, ext_partial, ext_count, coef_out, skip_lo, skip_hi);
   return nnue_launch_status("nnue_sgd_step");
 }
 
