@@ -137,6 +137,12 @@ def test_one_rank_over_rccl_with_the_collective_inside_the_graph(tmp_path, env):
     _run(tmp_path, 1, "nccl", True, {"NNUE_DP_FORCE_COLLECTIVES": "1", **env})
 
 
+def test_two_ranks_step_many_falls_back_to_single_steps_over_gloo(tmp_path):
+    """gloo collectives cannot be captured: step_many then runs its steps one by one (eager exchange between the local graph
+    and the update graph) and returns their losses -- the same trajectory."""
+    _run(tmp_path, 2, "gloo", True, {"TEST_STEP_MANY": "1"})
+
+
 def test_one_rank_over_rccl_two_steps_in_one_graph(tmp_path):
     """step_many under collectives: two consecutive steps, each with its all-reduce, captured and replayed as one hipGraph."""
     _run(tmp_path, 1, "nccl", True, {"NNUE_DP_FORCE_COLLECTIVES": "1", "TEST_STEP_MANY": "1"})
