@@ -93,9 +93,15 @@ def test_three_steps_at_the_baseline_shape_follow_the_oracle(name):
     model = model.to(DEV)
     tr = NnueTrainer(model, cfg["batch"], (cfg["image"], cfg["image"]), use_graph=True, input_slots=2, **OPT)
     # the path under test is the one the bench line reports
+    import os
+    if os.environ.get("NNUE_FT_PATH", "auto") not in ("auto", "mfma"):
+        pytest.skip("another FeatureTransformer kernel family is forced (NNUE_FT_PATH)")
     assert tr.ft_path == "mfma" and tr.use_graph
-    if name in ("c2", "c3"):
-        assert tr.fuse_l1 and tr.ride_dw1 and tr.defer_ste and tr.merge_backward
+    if name in ("c2", "c3"):  # every default fusion is on (a knob set to its non-default value switches its own off)
+        on = lambda k: os.environ.get(k, "1") != "0"  # noqa: E731
+        merged = os.environ.get("NNUE_FTM_SPLIT_BACKWARD", "0") != "1"
+        assert tr.merge_backward == merged and tr.ride_dw1 == (on("NNUE_FTM_RIDE_DW1") and merged)
+        assert tr.fuse_l1 == on("NNUE_FUSE_L1") and tr.defer_ste == on("NNUE_DEFER_STE")
     gen = torch.Generator().manual_seed(77)
     bufs = {}
     for s in range(3):
