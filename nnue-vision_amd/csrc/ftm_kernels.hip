@@ -805,6 +805,9 @@ __device__ __forceinline__ void gemm_tile_bf64(unsigned char* __restrict__ smem,
     const int gm = grp % groups_m, gk = grp / groups_m;
     return ((gk * 4 + (l >> 2)) * MB) + gm * 4 + (l & 3);
   };
+  // forward: the four groups of a row go to four consecutive lanes; the eight lanes of a ds_write_b128 group then hold two
+  // rows, which must differ in row / 2 (the swizzle term) or their chunks collide: bits 0 and 1 of the row index are swapped
+  auto a_row_of = [](int g) { const int x = g >> 2; return (x & ~3) | ((x & 1) << 1) | ((x >> 1) & 1); };
   constexpr int AGK = BM * 4 / 256;           // forward: 16-byte groups per thread (2 or 1)
   constexpr int ABLK = (BM / 4) * (KT / 8);   // weight gradient: 8 k x 4 m blocks (256 or 128: the first threads)
   u32x4 ra[AGK];
@@ -814,7 +817,7 @@ __device__ __forceinline__ void gemm_tile_bf64(unsigned char* __restrict__ smem,
     if constexpr (AKC) {
 #pragma unroll
       for (int i = 0; i < AGK; ++i) {
-        const int g = tid + 256 * i, row = g >> 2, k = k0 + (g & 3) * 16;
+        const int g = tid + 256 * i, row = a_row_of(g), k = k0 + (g & 3) * 16;
         ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsa, (m_base + row) * ma.ld + k, 0, 0);
       }
     } else {
@@ -836,7 +839,7 @@ __device__ __forceinline__ void gemm_tile_bf64(unsigned char* __restrict__ smem,
     if constexpr (AKC) {
 #pragma unroll
       for (int i = 0; i < AGK; ++i) {
-        const int g = tid + 256 * i, row = g >> 2, c = (g & 3) * 2;
+        const int g = tid + 256 * i, row = a_row_of(g), c = (g & 3) * 2;
         u32x4 lo, hi;
         unsigned a, b;
         bytes_to_bf16(ra[i][0], a, b); lo[0] = a; lo[1] = b;
@@ -958,7 +961,10 @@ constexpr int gemm_bf6_lds_bytes() { return 3 * (BM + BN) * KT * 2; }
 // rows of KT bf16 (128 or 64 bytes): two or four rows per 256-byte bank row, chunk index XOR-swizzled accordingly
 template <int KT>
 __device__ __forceinline__ int bf6_img(int row, int chunk) {
-  return row * (KT * 2) + ((chunk ^ (KT == 64 ? (row >> 1) & 7 : (row >> 2) & 3)) << 4);
+  // KT == 32: a ds_read_b128 lane group holds rows {0-3, 12-15} of one chunk and rows {4-11} of the next (the hardware's
+  // groups are {0-3, 12-15, 20-27}, ...), and four 64-byte rows share a 256-byte bank row, so the XOR term per block of four
+  // rows is {0, 3, 2, 1} -- with the obvious {0, 1, 2, 3} a third of the kernel's LDS cycles were conflicts (SQ_LDS_BANK_CONFLICT)
+  return row * (KT * 2) + ((chunk ^ (KT == 64 ? (row >> 1) & 7 : (4 - (row >> 2)) & 3)) << 4);
 }
 
 // 8 consecutive k (two float4) -> one 16-byte chunk of 8 bf16 per plane
