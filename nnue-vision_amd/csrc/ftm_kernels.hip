@@ -607,7 +607,10 @@ __device__ __forceinline__ void gemm_tile_bf(unsigned char* __restrict__ smem, c
   // that their 16-byte LDS stores (row n, chunk k/8, chunk XOR-swizzled by the row) fall into 16 different 16-byte slots:
   // with 16 n blocks x 1 k block per group the rows 4 j + e repeat modulo 16 and the stores were 4-way bank-conflicted.
   // A wave still reads 256 contiguous bytes of each of its k rows.
-  const int bn4 = (((lane & 3) | ((lane >> 4) << 2))) * 4, bk8 = (((lane >> 2) & 3) | (wave << 2)) * 8;
+  // (ds_write_b128 is served in groups of 8 consecutive lanes over a 128-byte window: those take 2 n blocks x 4 k blocks, rows
+  // r and r + 4 with four consecutive chunks each -- eight different slots; 4 n blocks x 2 k blocks put rows r and r + 8 on
+  // the same slot: a third of the 64-row forward's LDS cycles were conflicts)
+  const int bn4 = ((lane & 1) | ((lane >> 3) << 1)) * 4, bk8 = (((lane >> 1) & 3) | (wave << 2)) * 8;
   const int b_off = b_col(n_base + bn4) * 4;  // byte offset inside a row
   // A, forward (bytes contiguous along k): 16-byte groups, (row, 16 k); BM * 8 groups
   // A, weight gradient (bytes contiguous along m): thread = (k block of 8, m block of 4); BM / 4 x 16 blocks
@@ -618,8 +621,12 @@ __device__ __forceinline__ void gemm_tile_bf(unsigned char* __restrict__ smem, c
     const int grp = g >> 4, l = g & 15;  // 16 consecutive blocks = 4 m blocks x 4 k blocks
     const int groups_m = MB / 4;         // groups along m per 4 k blocks
     const int gm = grp % groups_m, gk = grp / groups_m;
-    return ((gk * 4 + (l >> 2)) * MB) + gm * 4 + (l & 3);
+    return ((gk * 4 + ((l >> 1) & 3)) * MB) + gm * 4 + ((l & 1) | ((l >> 3) << 1));  // 8 lanes: 2 m blocks x 4 k blocks (see above)
   };
+  // forward: 16 consecutive groups are two rows x eight 16-k groups, rows alternating lane by lane, so that the eight lanes of a
+  // ds_write_b128 group hold rows r, r + 1 with chunks {0, 2, 4, 6} (+1 for the second store): even and odd slots
+  auto akc_row = [](int g) { return ((g >> 4) << 1) | (g & 1); };
+  auto akc_grp = [](int g) { return (g >> 1) & 7; };
   constexpr int AGK = BM * 8 / 256;                 // forward: 16-byte loads per thread
   constexpr int AGR = (BM / 4) * 16 / 256 ? (BM / 4) * 16 / 256 : 1;  // weight gradient: 8 x 4 blocks per thread (BM = 32: half the threads)
   struct Regs {
@@ -633,7 +640,7 @@ __device__ __forceinline__ void gemm_tile_bf(unsigned char* __restrict__ smem, c
     if constexpr (AKC) {
 #pragma unroll
       for (int i = 0; i < AGK; ++i) {
-        const int g = tid + 256 * i, row = g >> 3, k = k0 + (g & 7) * 16;
+        const int g = tid + 256 * i, row = akc_row(g), k = k0 + akc_grp(g) * 16;
         ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsa, (m_base + row) * ma.ld + k, 0, 0);
       }
     } else {
@@ -662,7 +669,7 @@ __device__ __forceinline__ void gemm_tile_bf(unsigned char* __restrict__ smem, c
     if constexpr (AKC) {
 #pragma unroll
       for (int i = 0; i < AGK; ++i) {
-        const int g = tid + 256 * i, row = g >> 3, c = (g & 7) * 2;
+        const int g = tid + 256 * i, row = akc_row(g), c = akc_grp(g) * 2;
         u32x4 lo, hi;
         unsigned a, b;
         bytes_to_bf16(ra[i][0], a, b); lo[0] = a; lo[1] = b;
