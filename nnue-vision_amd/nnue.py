@@ -7,8 +7,11 @@ seed.  What differs is underneath: ``forward`` runs hand-written HIP kernels for
 ``nnue_hip`` (C ABI in include/nnue_hip.h); there is no per-sample Python loop, no data-dependent
 tensor shape and no host synchronisation in ``NNUE.forward``.
 
-GPU only: modules can be built, moved, (de)serialised and exported on the CPU, but ``forward`` on
-CPU tensors raises -- there is deliberately no fallback.
+Dispatch is by the *tensor's device*, never by what happens to be installed: a GPU tensor always takes the HIP
+kernels and raises ``NnueHipError`` when libnnue_hip.so is missing or stale (nothing falls back to anything).  A
+CPU tensor -- the reference's ``device`` fixture without a GPU (tests/conftest.py:157-160), BASELINE configs[0] --
+runs the same formulas as vectorised stock torch with autograd (``_host_*`` below): a convenience path for
+plumbing runs, not a measured one, never used by the trainer or bench.py, and independent of ``oracle/``.
 
 Reference map (file:line under the reference root):
   GridFeatureSet nnue.py:81-90 | LossParams :62-72 | StraightThroughBinary :15-59
@@ -21,6 +24,7 @@ from typing import Optional
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from nnue_hip import lib as _lib
 from nnue_hip import ops as _ops
@@ -83,6 +87,32 @@ def binary_activation_ste(x, threshold=0.0):
     return StraightThroughBinary.apply(x, threshold)
 
 
+# ---- CPU tensors: the module formulas in stock torch (device dispatch, see the module docstring) -------------------
+def _host_feature_transformer(idx, val, weight, bias):
+    """out[b] = bias + sum_i val[b,i] * weight[clamp(idx[b,i], 0, F-1)] over idx >= 0 (nnue.py:686-710) as a
+    coefficient matrix times the table; repeats accumulate, the values keep their gradient."""
+    keep = idx >= 0
+    rows = torch.where(keep, idx.clamp(0, weight.shape[0] - 1), torch.zeros_like(idx))
+    coef = torch.zeros(idx.shape[0], weight.shape[0], dtype=val.dtype, device=val.device)
+    coef = coef.scatter_add(1, rows, torch.where(keep, val, torch.zeros_like(val)))
+    return coef @ weight + bias
+
+
+def _host_classifier(x, linears, clip, bucket=None):
+    """Linear / ReLU (or clamp(0, clip)) x 2 / Linear (nnue.py:728-738); stacked weights take each sample's own stack."""
+    act = (lambda t: t.clamp(0.0, clip)) if clip else F.relu
+    (a, b, c) = linears
+    if a.weight.dim() == 2:
+        return F.linear(act(F.linear(act(F.linear(x, a.weight, a.bias)), b.weight, b.bias)), c.weight, c.bias)
+    out = x.new_zeros(x.shape[0], c.weight.shape[1])
+    for k in range(a.weight.shape[0]):
+        rows = (bucket == k).nonzero(as_tuple=True)[0]
+        if rows.numel():
+            h = act(F.linear(act(F.linear(x[rows], a.weight[k], a.bias[k])), b.weight[k], b.bias[k]))
+            out = out.index_add(0, rows, F.linear(h, c.weight[k], c.bias[k]))
+    return out
+
+
 class FeatureTransformer(nn.Module):
     """Sparse input layer: out[b] = bias + sum_i val[b,i] * weight[clamp(idx[b,i])]  (nnue.py:674-710)."""
 
@@ -96,6 +126,8 @@ class FeatureTransformer(nn.Module):
     def forward(self, feature_indices: torch.Tensor, feature_values: torch.Tensor) -> torch.Tensor:
         """feature_indices int64 [B,M] (negative = padding, >= num_features clamps to the last row, any
         order, repeats accumulate); feature_values float32 [B,M].  Returns float32 [B, output_size]."""
+        if not feature_values.is_cuda:
+            return _host_feature_transformer(feature_indices, feature_values, self.weight, self.bias)
         return _ops.FeatureTransformerFn.apply(feature_indices, feature_values, self.weight, self.bias)
 
 
@@ -122,6 +154,8 @@ class SimpleClassifier(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         a, b, c = self._linears()
         lead = x.shape[:-1]
+        if not x.is_cuda:
+            return _host_classifier(x, (a, b, c), self.clip_activations)
         y = _ops.ClassifierFn.apply(x.reshape(-1, x.shape[-1]), a.weight, a.bias, b.weight, b.bias, c.weight, c.bias,
                                     False, float(self.clip_activations or 0.0), None)
         return y.reshape(*lead, y.shape[-1])
@@ -174,6 +208,8 @@ class BucketedClassifier(nn.Module):
     def forward(self, x: torch.Tensor, bucket: torch.Tensor) -> torch.Tensor:
         """x [B, L1] (the pairwise block's output), bucket integer [B] in [0, K): the stack of each sample."""
         a, b, c = self._linears()
+        if not x.is_cuda:
+            return _host_classifier(x.reshape(-1, x.shape[-1]), (a, b, c), self.clip_activations, bucket.reshape(-1))
         return _ops.ClassifierFn.apply(x.reshape(-1, x.shape[-1]), a.weight, a.bias, b.weight, b.bias, c.weight, c.bias,
                                        False, float(self.clip_activations or 0.0), bucket.reshape(-1))
 
@@ -230,9 +266,31 @@ class NNUE(nn.Module):
     # ---- hot path ----------------------------------------------------------------------------
     def forward(self, images: torch.Tensor) -> torch.Tensor:
         a, b, c = self.classifier._linears()
+        if not images.is_cuda:
+            return self._host_forward(images)
         return _ops.NnueFn.apply(images, self.visual_threshold, self.conv.weight, self.input.weight, self.input.bias,
                                  a.weight, a.bias, b.weight, b.bias, c.weight, c.bias, int(self.conv.stride[0]),
                                  float(self.classifier.clip_activations or 0.0))
+
+    def _host_forward(self, images: torch.Tensor) -> torch.Tensor:
+        """NNUE.forward for CPU tensors (nnue.py:637-671) without the per-sample loops: the active-feature gather is the
+        {0,1} map times the table, ids past the table fold into its last row (nnue.py:701).  As in the reference the
+        map's gradient exists at active positions only (the values are gathered from them, nnue.py:628-633)."""
+        x = self.conv(images)
+        bits = StraightThroughBinary.apply(x, self.visual_threshold.view(1, -1, 1, 1))
+        flat = bits.reshape(bits.shape[0], -1)
+        flat = flat * flat.detach()  # same values; gradient only where the feature is active
+        w, rows = self.input.weight, self.input.weight.shape[0]
+        if flat.shape[1] < rows:
+            ft = flat @ w[:flat.shape[1]] + self.input.bias
+        else:
+            ft = flat[:, :rows - 1] @ w[:rows - 1] + flat[:, rows - 1:].sum(dim=1, keepdim=True) * w[rows - 1] + self.input.bias
+        s0, s1 = torch.split(ft, self.l1_size // 2, dim=1)
+        l0 = torch.cat([s0 * s1, s0], dim=1)
+        if self.num_ls_buckets == 1:
+            return self.classifier(l0)
+        counts = (flat.detach() > 0.5).sum(dim=1)
+        return self.classifier(l0, bucket_of(counts, self.num_ls_buckets, flat.shape[1]))
 
     def _to_sparse_features(self, binary_features: torch.Tensor):
         """Reference-format sparse view of a {0,1} map: (idx int64 [B,M] padded -1, val float32 [B,M]),
@@ -242,6 +300,15 @@ class NNUE(nn.Module):
         ``binary_features`` at the active positions."""
         bsz = binary_features.shape[0]
         flat = binary_features.reshape(bsz, -1).to(torch.float32)
+        if not flat.is_cuda:
+            on = flat.detach() > 0.5
+            n = on.sum(dim=1)
+            width = max(int(n.max()) if bsz else 0, 1)
+            order = torch.argsort((~on).to(torch.int8), dim=1, stable=True)[:, :width]  # active positions first, ascending
+            live = torch.arange(width).unsqueeze(0) < n.unsqueeze(1)
+            idx = torch.where(live, order, torch.full_like(order, -1))
+            val = torch.where(live, flat.gather(1, order), flat.new_zeros(()))
+            return idx, val
         with torch.no_grad():
             half = torch.full((1,), 0.5, dtype=torch.float32, device=flat.device)
             act = _lib.binarize_features(flat.detach().reshape(bsz, 1, 1, -1), half, max(int(flat.shape[-1]), 1))

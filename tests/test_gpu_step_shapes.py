@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 import nnue
 import nnue_oracle as orc
-from conftest import assert_close_grad
+from conftest import assert_close_grad, assert_close_logits
 from nnue_hip.trainer import NnueTrainer
 
 pytestmark = pytest.mark.gpu
@@ -107,7 +107,7 @@ def test_three_steps_at_the_baseline_shape_follow_the_oracle(name):
     for s in range(3):
         images, labels = clean_batch(cfg, params, stride, gen)
         before = {k: v.clone() for k, v in params.items()}
-        _, ref_loss, ref_grads, keep = orc.loss_and_grads_explicit(params, images, labels, stride, cfg.get("clip"))
+        ref_logits, ref_loss, ref_grads, keep = orc.loss_and_grads_explicit(params, images, labels, stride, cfg.get("clip"))
         if cfg.get("spread") and s == 0:
             assert len(set(keep["bucket"].tolist())) == cfg["buckets"], "the spread batch must reach every layer stack"
         ref_norm = orc.sgd_step(params, ref_grads, bufs, OPT["lr"], OPT["momentum"], OPT["weight_decay"], OPT["max_grad_norm"])
@@ -117,6 +117,8 @@ def test_three_steps_at_the_baseline_shape_follow_the_oracle(name):
         torch.cuda.synchronize()
         n_mean, n_max = tr.active_stats()
         assert n_max == int(keep["n"].max()) and abs(n_mean - float(keep["n"].float().mean())) < 1e-2, "feature counts differ"
+        # the north star's own acceptance sentence: every logit within 1e-4 * max(1, |logit|) of the reference forward
+        assert_close_logits(tr.logits, ref_logits, f"{name} step {s} logits")
         assert abs(float(loss) - float(ref_loss)) <= 1e-4 * max(1.0, abs(float(ref_loss))), (s, float(loss), float(ref_loss))
         assert abs(float(tr.grad_norm) - float(ref_norm)) <= 1e-4 * float(ref_norm), (s, float(tr.grad_norm), float(ref_norm))
         if getattr(tr, "grads_materialised", True):

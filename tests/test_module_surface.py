@@ -87,15 +87,16 @@ def test_rejected_configurations():
         nnue.EtinyNet()
 
 
-@pytest.mark.skipif(has_gpu(), reason="checks the no-GPU failure mode")
-def test_forward_without_gpu_fails_loudly():
+def test_cpu_tensors_run_and_the_gpu_layer_refuses_them():
+    """Device dispatch (SURVEY 8b): CPU tensors run the stock-torch formulas (tests/test_host_modules.py pins them);
+    the HIP layer itself never accepts a CPU tensor."""
+    from nnue_hip import lib
     m = nnue.NNUE(nnue.GridFeatureSet(4, 8), 32, 4, 4, num_classes=10)
+    assert m(torch.randn(2, 3, 32, 32)).shape == (2, 10)
+    assert m.input(torch.zeros(2, 3, dtype=torch.long), torch.ones(2, 3)).shape == (2, 32)
+    assert m.classifier(torch.randn(2, 32)).shape == (2, 10)
     with pytest.raises(NnueHipError, match="GPU only"):
-        m(torch.randn(2, 3, 32, 32))
-    with pytest.raises(NnueHipError):
-        m.input(torch.zeros(2, 3, dtype=torch.long), torch.ones(2, 3))
-    with pytest.raises(NnueHipError):
-        m.classifier(torch.randn(2, 32))
+        lib.conv3x3_forward(torch.randn(2, 3, 32, 32), m.conv.weight, 3)
 
 
 def test_clip_weights_and_quantized_data_on_cpu():
