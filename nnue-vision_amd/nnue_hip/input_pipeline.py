@@ -112,6 +112,14 @@ def train_epoch(trainer, loader: GpuLoader):
             total += trainer.step(slot=s)
         else:
             images, labels = ds.batch(idx)
-            total += trainer.step(images, labels, slot=s)
+            count = None
+            if trainer.dp.world > 1:
+                # short last batch with ranks: the exact mean needs the number of real samples over ALL ranks (every
+                # rank's loader yields the same number of batches; a rank may hold fewer or no samples in the last one)
+                import torch.distributed as dist
+                cnt = torch.tensor([int(idx.numel())], dtype=torch.int64, device=trainer.dev if trainer.dp.backend == "nccl" else "cpu")
+                dist.all_reduce(cnt, group=trainer.dp.group)
+                count = int(cnt.item())
+            total += trainer.step(images, labels, slot=s, global_count=count)
         i += 1
     return total, n

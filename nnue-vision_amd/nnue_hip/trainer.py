@@ -293,6 +293,9 @@ class NnueTrainer:
             self.sq_range = (off, off + rows * self.L1)
             self.gram = torch.zeros((lib.ftm_gram_scratch(self.fm),), **f32)
             self.clip_coef = torch.ones((), **f32)
+        # With the fused table update ``model.input.weight.grad`` (a view of flat_grads) is never written: rows the product
+        # covers stay at the zeros they were allocated with.  ``grads_materialised`` says so; callers that want the table's
+        # gradient for logging or custom clipping set NNUE_FUSE_TABLE_UPDATE=0.
         self.grads_materialised = not self.fuse_table_update
         self.d_z1 = self.ft_rider = None
         if self.ride_dw1 and self.K == 1:
@@ -727,7 +730,14 @@ class NnueTrainer:
     def optimizer_state_dict(self) -> dict:
         """The optimizer state in torch.optim's own state_dict format (SGD momentum buffers, or Adam's step /
         exp_avg / exp_avg_sq), indexed like ``model.parameters()`` -- what checkpoint_manager.py:45-51 stores and
-        ``optimizer.load_state_dict`` (checkpoint_manager.py:75-85) expects."""
+        ``optimizer.load_state_dict`` (checkpoint_manager.py:75-85) expects.
+
+        With the sharded update (more than one rank, bandwidth-sized buffers) every rank owns only its shard of the
+        momentum, so this call first all-gathers the shards: it is then a COLLECTIVE and every rank must make it (the
+        train loop does: all ranks reach the same best-F1 decision)."""
+        if self.sharded_update and self.flat_momentum is not None and self.dp.world > 1 and self.steps_done > 0:
+            torch.cuda.current_stream(self.dev).synchronize()
+            self.dp.all_gather(self.flat_momentum, self.dp.shard_of(self.flat_momentum))
         params = list(self.model.parameters())
         if self.optimizer == "adam":
             opt = torch.optim.Adam(params, lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay)

@@ -34,6 +34,12 @@ def _build(device="cuda"):
     return nnue.NNUE(nnue.GridFeatureSet(CFG["grid"], CFG["fps"]), CFG["l1"], CFG["l2"], CFG["l3"], num_classes=CFG["classes"]).to(device)
 
 
+def _momentum(tr):
+    """All momentum buffers of the checkpointed optimizer state (torch.optim's format), parameter order."""
+    sd = tr.optimizer_state_dict()
+    return torch.cat([sd["state"][i]["momentum_buffer"].flatten().cpu() for i in sorted(sd["state"])])
+
+
 def _worker(rank, port, out_dir, world, backend, use_graph, env, short_last):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", **env)
@@ -75,7 +81,8 @@ def _worker(rank, port, out_dir, world, backend, use_graph, env, short_last):
             else:
                 losses.append(float(tr.step(images[sl].to(tr.dev), labels[sl].to(tr.dev), slot=s % 2)))
         torch.cuda.synchronize()
-        torch.save({"flat": tr.flat_params.cpu(), "norm": float(tr.grad_norm), "losses": losses}, Path(out_dir) / f"rank{rank}.pt")
+        torch.save({"flat": tr.flat_params.cpu(), "norm": float(tr.grad_norm), "losses": losses, "momentum": _momentum(tr)},
+                   Path(out_dir) / f"rank{rank}.pt")
     finally:
         dist.destroy_process_group()
 
@@ -89,7 +96,7 @@ def _reference(use_graph, short_last):
         images, labels = _batch(s)
         n = SHORT if (short_last and s == STEPS - 1) else GLOBAL_BATCH
         losses.append(float(tr.step(images[:n].cuda(), labels[:n].cuda())))
-    return tr.flat_params.cpu(), float(tr.grad_norm), losses, tr.layout.count
+    return tr.flat_params.cpu(), float(tr.grad_norm), losses, tr.layout.count, _momentum(tr)
 
 
 def _run(tmp_path, world, backend, use_graph, env, short_last=False):
@@ -101,7 +108,13 @@ def _run(tmp_path, world, backend, use_graph, env, short_last=False):
     for r in ranks[1:]:
         assert torch.equal(ranks[0]["flat"], r["flat"]), "replicas diverged"
         assert ranks[0]["norm"] == r["norm"]
-    ref, ref_norm, ref_losses, count = _reference(use_graph, short_last)
+    ref, ref_norm, ref_losses, count, ref_mom = _reference(use_graph, short_last)
+    if "momentum" in ranks[0]:
+        # what a checkpoint stores (checkpoint_manager.py:45-51): under the sharded update a rank owns one shard of the
+        # momentum, optimizer_state_dict() gathers the others
+        for r in ranks:
+            assert r["momentum"].shape == ref_mom.shape
+            assert float((r["momentum"] - ref_mom).abs().max()) <= 2e-4 * float(ref_mom.abs().max()), "checkpointed momentum differs"
     got = ranks[0]["flat"][:count]  # the flat buffers are padded to a multiple of 4 * world
     scale = float(ref.abs().max())
     assert float((got - ref[:got.numel()]).abs().max()) <= 2e-4 * scale

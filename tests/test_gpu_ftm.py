@@ -59,12 +59,11 @@ def test_ftm_kernels_against_float64(hip, shape, density):
     active = (conv_out > thr.view(1, -1, 1, 1)).reshape(b, -1)
     assert torch.equal(fm.n.cpu(), ref_n) and torch.equal(fm.sink.cpu(), ref_sink) and torch.equal(fm.bits.cpu(), active.to(torch.uint8))
     out = hip.ftm_forward(g(weight), g(bias), fm)
-    if fps * gh * gw >= 16384:
-        # sums of tens of thousands of float32 terms: an element near zero carries the rounding of partial sums of size
-        # sqrt(n) * 0.1, so the bar is taken against the tensor's scale (as for gradients), 1e-5 of it
-        assert_close_grad(out, ref_out, "out (big map)", rtol=1e-5)
-    else:
-        assert_close_logits(out, ref_out, "out", rtol=2e-5)
+    # element by element against the float64 value.  Sums of tens of thousands of float32 terms (the big maps) are held to
+    # the north star's own bar, 1e-4 * max(1, |ref|); measured there (profiles/r03a_ft_err.json): worst element 0.79 of
+    # that bar, and never worse than a float32 CPU product of the same operands (1.7e-4 vs 1.3e-4 absolute at |ref| = 880).
+    # Small maps keep the 5x sharper bar they have always met.
+    assert_close_logits(out, ref_out, "out", rtol=1e-4 if fps * gh * gw >= 16384 else 2e-5)
     d_w, d_b = hip.ftm_backward_weight(g(d_out), fm)
     assert_close_grad(d_w, ref_dw, "d_weight", rtol=2e-5)
     assert_close_grad(d_b, ref_db, "d_bias", rtol=2e-5)
