@@ -57,10 +57,12 @@ def parse():
     ap.add_argument("--density", type=float, default=None,
                     help="override visual_threshold per channel so about this fraction of features is active (SURVEY 8d sweep); "
                          "default: the reference's 0.1 threshold (~0.43)")
-    ap.add_argument("--spread", action="store_true",
-                    help="bucketed workloads: give every sample its own offset and gain (and make the conv weights positive) so "
-                         "that the active-feature counts, and with them the layer-stack buckets, cover the whole range; default "
-                         "randn images put nearly every sample into one bucket")
+    ap.add_argument("--spread", action="store_true", default=None,
+                    help="give every sample its own offset and gain (and make the conv weights positive) so that the "
+                         "active-feature counts, and with them the layer-stack buckets, cover the whole range.  DEFAULT for the "
+                         "bucketed workload (c3): plain randn images put every sample into one bucket, which would time 8 stacks "
+                         "of weights on a one-stack workload; the line then also carries config.single_bucket_images_per_sec")
+    ap.add_argument("--no-spread", dest="spread", action="store_false", help="plain randn images also for the bucketed workload")
     ap.add_argument("--steps-per-graph", type=int, default=0,
                     help="consecutive steps (each on the next input slot) replayed as one hipGraph (NnueTrainer.step_many); "
                          "steps left over after the whole groups run as single-step graphs; 1 = one graph launch per step; "
@@ -185,6 +187,8 @@ def main():
     from nnue_hip.trainer import NnueTrainer
 
     cfg = WORKLOADS[args.workload]
+    if args.spread is None:
+        args.spread = cfg.get("buckets", 1) > 1
     torch.manual_seed(0)
     model = nnue.NNUE(nnue.GridFeatureSet(cfg["grid"], cfg["fps"]), cfg["l1"], cfg["l2"], cfg["l3"],
                       num_classes=cfg["classes"], input_size=cfg["image"], num_ls_buckets=cfg.get("buckets", 1),
@@ -279,10 +283,14 @@ def main():
     merged = trainer.use_mfma and trainer.merge_backward
     bwd_entry = f"{ftp}_backward_bucketed" if (merged and trainer.K > 1) else f"{ftp}_backward"
     names += [bwd_entry] if merged else [f"{ftp}_backward_weight", f"{ftp}_backward_values"]
-    if getattr(trainer, "fuse_table_update", False):  # weight gradient formed and consumed in the update (no d_weight)
+    factor_exchange = bool(getattr(trainer, "factor_exchange", False))  # data parallel: the gradient's factors are gathered, same fused update
+    fused_update = bool(getattr(trainer, "fuse_table_update", False)) or factor_exchange
+    if fused_update:  # weight gradient formed and consumed in the update (no d_weight)
         names = [n for n in names if n not in (f"{ftp}_backward", f"{ftp}_backward_bucketed", f"{ftp}_backward_weight")]
-        names += [f"{ftp}_backward_values", f"{ftp}_gram_sqnorm", f"{ftp}_backward_tail_rows", f"{ftp}_backward_weight_update"]
+        names += [f"{ftp}_backward_values", f"{ftp}_backward_tail_rows"] + (["nnue_dp_factor_pack", "nnue_dp_factor_unpack"] if factor_exchange else [])
+        names += [f"{ftp}_gram_sqnorm", f"{ftp}_backward_weight_update"]
         names = list(dict.fromkeys(names))
+        merged = False
     names += ["nnue_ste_conv_backward", "nnue_sgd_step"]
     timers = {k: [] for k in names}
     isteps = max(5, min(50, args.steps))
@@ -311,10 +319,9 @@ def main():
         alg[fwd_entry] = alg.pop(f"{ftp}_forward")
     if merged and bwd_entry != f"{ftp}_backward":
         alg[bwd_entry] = alg.pop(f"{ftp}_backward")
-    fused_update = getattr(trainer, "fuse_table_update", False)
     if fused_update:  # value gradient as its own launch; the weight gradient is formed inside the update product
         alg = {fwd_entry: (n_mean + 1) * row * B, f"{ftp}_backward_values": (n_mean + 1) * row * B,
-               f"{ftp}_backward_weight_update": n_mean * row * B}
+               f"{ftp}_backward_weight_update": n_mean * row * B * (world if factor_exchange else 1)}
     kernels = {k: {"avg_us": round(dur_us[k], 2), **({"alg_GBps": round(alg[k] / dur_us[k] * 1e-3, 1)} if k in alg and dur_us[k] > 0 else {})}
                for k in names}
     KERNEL_OF = {  # C entry point -> (kernel name prefix, substring) in rocprof / PMC summaries
@@ -385,7 +392,9 @@ def main():
             f"{ftp}_forward_l1": ([("bf16" if uses(0) else "f32", f_fwd), ("f32", f_l1)], tbl + mp + act + (L1 // 64) * B * L2 * 4.0),
             f"{ftp}_backward_weight": ([("bf16" if uses(1) else "f32", f_w)], mp + act + tbl),
             f"{ftp}_backward_values": ([("bf16x6" if uses(4) else "f32", f_v)], act + F * L1 * 4.0 + mp + B * P * 4.0),
-            f"{ftp}_backward_weight_update": ([("bf16", f_w)], mp + act + 2 * tbl + (2 * tbl if OPT["momentum"] else 0)),
+            # (under the factor exchange the product contracts the GLOBAL batch: world x the flops, map and d_ft rows)
+            f"{ftp}_backward_weight_update": ([("bf16", f_w * (world if factor_exchange else 1))],
+                                              (mp + act) * (world if factor_exchange else 1) + 2 * tbl + (2 * tbl if OPT["momentum"] else 0)),
         }
         bw = [("bf16" if uses(2) else "f32", f_w), ("bf16x6" if uses(5) else "f32", f_v)] + ([("f32", f_l1)] if getattr(trainer, "ride_dw1", False) else [])
         work[f"{ftp}_backward"] = (bw, 2 * mp + act + F * L1 * 4.0 + tbl + B * P * 4.0)
@@ -404,10 +413,16 @@ def main():
                                   for u, f in units],
                   "ideal_us": {"mfma": round(t_mfma * 1e6, 2), "hbm": round(t_hbm * 1e6, 2)},
                   "avg_launch_us": round(dur_us[dom], 2), "rocprof_avg_us": rp["us"] if rp else None, "rocprof_source": rp["source"] if rp else None,
-                  "alg_bytes_per_launch": int(alg[dom]), "alg_GBps": round(alg_rate, 1)}
+                  "alg_bytes_per_launch": int(alg[dom]), "alg_GBps": round(alg_rate, 1),
+                  # SURVEY 8d's "one table row per gathered id" prices a gather; a product re-uses a staged row across the
+                  # samples of a tile, so for this path the algorithmic-byte rate is NOT a lower bound on traffic (it exceeds
+                  # the HBM peak while the table is cache-resident) -- the bound is the one reported in bound/peak/frac
+                  "alg_is_bound": False}
         if t_hbm >= t_mfma:
             rate = comp_bytes / dur / 1e9 if dur > 0 else 0.0
-            roofline = {"bound": "hbm", "achieved": round(rate, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(rate / HBM_PEAK_GBS, 4), **common,
+            roofline = {"bound": "hbm", "achieved": round(rate, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(rate / HBM_PEAK_GBS, 4),
+                        # the same fraction with the kernel's average duration in the committed rocprofv3 summary instead of this run's events
+                        "frac_rocprof": round(comp_bytes / (rp["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if rp else None, **common,
                         "regime": "compulsory bytes of the launch (table %.1f MB streamed once, parameters and momentum read and written where the "
                                   "update is fused) / HIP-event duration; the matrix work of the launch would take %.1f us at its units' peaks"
                                   % (table_mb, t_mfma * 1e6)}
@@ -416,6 +431,7 @@ def main():
             achieved = useful / dur / 1e12 if dur > 0 else 0.0
             roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(blended, 1), "unit": "TFLOP/s",
                         "frac": round(achieved / blended, 4),
+                        "frac_rocprof": round(useful / (rp["us"] * 1e-6) / 1e12 / blended, 4) if rp else None,
                         "frac_of_f32_mfma_peak": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),  # round 1's pricing of the same launch, for comparison
                         **common,
                         "regime": "useful flops of the products in the launch (2 M N K over the whole map) / HIP-event duration, against the "
@@ -424,13 +440,35 @@ def main():
     else:
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(alg_rate, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(alg_rate / HBM_PEAK_GBS, 4), "traffic": (pmc_traffic(dom) or {}).get("bytes"),
-                    "traffic_detail": pmc_traffic(dom),
+                    "traffic_detail": pmc_traffic(dom), "alg_is_bound": True,
                     "alg_bytes_per_launch": int(alg[dom]), "avg_launch_us": round(dur_us[dom], 2),
                     "regime": ("table %.1f MB is L2/Infinity-Cache resident: algorithmic rate is cache bandwidth and may exceed the HBM peak"
                                % table_mb) if table_mb < 200 else "table %.0f MB exceeds the Infinity Cache: HBM-bound" % table_mb}
 
     # ---- the same step with the LDS-staged gather kernels (the form SURVEY 8d prices against the HBM roofline), same
     # process, same synthetic batches: images/s and the algorithmic-byte rate of its dominant FT kernel
+    # ---- bucketed workload: the same step on plain randn images (every sample lands in ONE layer stack), same process
+    single_bucket = None
+    if world == 1 and args.spread and cfg.get("buckets", 1) > 1 and args.density is None:
+        torch.manual_seed(0)
+        model_s = nnue.NNUE(nnue.GridFeatureSet(cfg["grid"], cfg["fps"]), cfg["l1"], cfg["l2"], cfg["l3"], num_classes=cfg["classes"],
+                            input_size=cfg["image"], num_ls_buckets=cfg["buckets"], clip_activations=cfg.get("clip")).to(dev)
+        ts = NnueTrainer(model_s, B, (cfg["image"], cfg["image"]), group=None, use_graph=not args.no_graph, input_slots=SLOTS, **OPT)
+        gs = torch.Generator().manual_seed(1234)
+        for images, labels in ts.inputs:
+            images.copy_(torch.randn(B, 3, cfg["image"], cfg["image"], generator=gs))
+            labels.copy_(torch.randint(0, cfg["classes"], (B,), generator=gs))
+        set_up(ts)
+        run_steps(ts, max(5, min(args.warmup, 30)))
+        torch.cuda.synchronize(dev)
+        ts0 = time.perf_counter()
+        run_steps(ts, args.steps)
+        torch.cuda.synchronize(dev)
+        s_elapsed = time.perf_counter() - ts0
+        single_bucket = {"images_per_sec": round(B * args.steps / s_elapsed, 1), "ms_per_step": round(s_elapsed * 1e3 / args.steps, 4),
+                         "samples_per_bucket_last_batch": torch.bincount(ts.bucket_plan.bucket.long(), minlength=ts.K).tolist()}
+        del ts, model_s
+
     gather = None
     if world == 1 and trainer.ft_path == "mfma" and not args.no_gather_compare and os.environ.get("NNUE_FT_PATH", "auto") == "auto":
         os.environ["NNUE_FT_PATH"] = "bits"
@@ -506,6 +544,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
+            "timed_s": round(elapsed, 6),  # wall time of the timed region (K steps between the two barriers, max over ranks)
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -521,7 +560,10 @@ def main():
                        "mean_active_features": round(n_mean, 1), "max_active_features": n_max,
                        "active_density": round(n_mean / ((cfg["image"] - 1) // max(1, (cfg["image"] - 1) // (cfg["grid"] - 1)) + 1) ** 2 / cfg["fps"], 4),
                        "eager_ms_per_step_instrumented": round(eager_ms, 4), "loss_after": round(loss_after, 4),
-                       **({"num_ls_buckets": trainer.K, "samples_per_bucket_last_batch": bucket_hist} if bucket_hist is not None else {})},
+                       **({"num_ls_buckets": trainer.K, "samples_per_bucket_last_batch": bucket_hist} if bucket_hist is not None else {}),
+                       # the same 8-stack model on plain randn images, where one stack takes the whole batch
+                       **({"single_bucket_images_per_sec": single_bucket["images_per_sec"], "single_bucket": single_bucket}
+                          if single_bucket is not None else {})},
             "roofline": roofline,
             "kernels": kernels,
         }

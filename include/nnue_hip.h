@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 25
+#define NNUE_HIP_ABI_VERSION 26
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -484,6 +484,29 @@ int64_t nnue_engine_scratch(const nnue_engine_model* m, int B);
 int nnue_engine_evaluate_logits(const nnue_engine_model* m, const float* images, int B, int H, int W,
                                 float* logits, float* density, void* scratch, int64_t scratch_bytes,
                                 nnue_stream_t stream);
+
+/* Data parallel for bandwidth-sized tables ("exchange only touched rows"; the reference itself is single-device,
+ * train.py:263).  The table's weight gradient of the GLOBAL batch is d_W = A^T D with A the {0,1} map [world*B][P] and
+ * D = d_ft [world*B][L1]: the ranks all-gather those FACTORS (the map as one bit per position) instead of reducing the
+ * F x L1 product (1.5 MB per rank instead of 269 MB at the 224x224 configuration), and every rank runs the single-rank fused
+ * path on them (nnue_ftm_gram_sqnorm, nnue_sgd_step, nnue_ftm_backward_weight_update with B = world*B): the gradient of the
+ * mean loss over the global batch and clip_grad_norm_ on its global norm (train.py:359-366), identical on every rank.
+ * One rank's chunk of the all-gather (byte offsets from nnue_dp_factor_offset, which = 0 d_ft, 1 sink, 2 small, 3 bits):
+ *     d_ft [B][L1] f32 | sink [B] f32 | small [small_count] f32 | map bits [B][ceil(P/128)*16] (bit k of byte j = position 8j+k)
+ * d_ft and sink are written in place by their producers (the trainer's buffers are views of its own chunk).
+ * nnue_dp_factor_pack fills the bits from the byte map and "small" with every gradient the product does not cover:
+ * grads[0, head_count) ++ grads[tail_lo, tail_lo + tail_count) of the flat gradient buffer (threshold and conv weight;
+ * table rows >= direct, bias, classifier).  nnue_dp_factor_unpack takes the world gathered chunks (rank-major) and leaves
+ * the global byte map g_bits [world*B][P], g_sink [world*B], g_dft [world*B][L1], and in grads the SUM of the ranks' small
+ * parts in rank order (the all-reduce of the small gradients as a deterministic reduction: one collective per step).
+ * P and L1 multiples of 4; all pointers 16-byte aligned. */
+int64_t nnue_dp_factor_chunk_bytes(int B, int P, int L1, int64_t small_count);
+int64_t nnue_dp_factor_offset(int which, int B, int P, int L1, int64_t small_count);
+int nnue_dp_factor_pack(const uint8_t* bits, const float* grads, int64_t head_count, int64_t tail_lo, int64_t tail_count,
+                        int B, int P, int L1, void* chunk, nnue_stream_t stream);
+/* (train.py:359-366 over the global batch, see above) */
+int nnue_dp_factor_unpack(const void* chunks, int world, int B, int P, int L1, int64_t head_count, int64_t tail_lo,
+                          int64_t tail_count, uint8_t* g_bits, float* g_sink, float* g_dft, float* grads, nnue_stream_t stream);
 
 /* The first stage of the clip norm below, alone: nparts block partials of sum g^2 (unscaled, fixed order) -- what a rank contributes
  * when the clip norm of clip_grad_norm_ (train.py:363-364) spans gradient shards held by different ranks: the partials are

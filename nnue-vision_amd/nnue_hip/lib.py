@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -117,6 +117,10 @@ SIGNATURES = {
                                _c_p, _c_p, _c_i64, _c_p, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_i64, _c_i64, _c_p, _c_int, _c_p]),
     "nnue_ftm_uses_bf16": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int]),
     "nnue_sqnorm_partials": (_c_int, [_c_p, _c_i64, _c_p, _c_int, _c_p]),
+    "nnue_dp_factor_chunk_bytes": (_c_i64, [_c_int, _c_int, _c_int, _c_i64]),
+    "nnue_dp_factor_offset": (_c_i64, [_c_int, _c_int, _c_int, _c_int, _c_i64]),
+    "nnue_dp_factor_pack": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_p, _c_p]),
+    "nnue_dp_factor_unpack": (_c_int, [_c_p, _c_int, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "nnue_ftm_gram_sq_count": (_c_i64, [_c_int, _c_int]),
     "nnue_ftm_gram_scratch": (_c_i64, [_c_int, _c_int, _c_int]),
     "nnue_ftm_gram_sqnorm": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
@@ -172,10 +176,38 @@ class record_calls:
         return False
 
 
+_timing: Optional[dict] = None  # when a dict {entry point: list}: direct calls of those entry points are bracketed with events
+
+
+class time_calls:
+    """Context manager: like ``run_plan(..., timers)`` for calls made directly through the wrappers (the exchange-and-update
+    tail of a data-parallel step is not a recorded plan): (start, end) events on the current stream around each named call."""
+
+    def __init__(self, timers):
+        self.timers = timers
+
+    def __enter__(self):
+        global _timing
+        self.prev, _timing = _timing, self.timers
+        return self.timers
+
+    def __exit__(self, *exc):
+        global _timing
+        _timing = self.prev
+        return False
+
+
 def _call(name: str, *args) -> None:
     lib = load()
     fn = getattr(lib, name)
-    rc = fn(*args)
+    if _timing is not None and name in _timing:
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        rc = fn(*args)
+        t1.record()
+        _timing[name].append((t0, t1))
+    else:
+        rc = fn(*args)
     if rc != 0:
         raise NnueHipError(f"{name} failed (code {rc}): {lib.nnue_hip_last_error().decode()}")
     if _recording is not None:
@@ -991,6 +1023,45 @@ def ftm_backward_weight_update(d_out: torch.Tensor, fm: "FeatureMatrix", weight:
     _call("nnue_ftm_backward_weight_update", fm.bits.data_ptr(), d_out.data_ptr(), b, fm.num_rows, fm.positions, l1, weight.data_ptr(),
           _ptr(momentum_rows), coef.data_ptr(), float(lr), float(momentum), float(weight_decay), float(grad_scale),
           int(bool(first_step)), _stream(d_out))
+
+
+class FactorExchange:
+    """Buffers of the factor exchange (include/nnue_hip.h, nnue_dp_factor_*): ``chunks`` uint8 [world][chunk_bytes] is the
+    all-gather's receive buffer, ``own`` this rank's slice of it (sent in place); ``d_ft`` / ``sink`` are float views of the
+    own chunk that the step's kernels write directly; ``g_*`` the global factors every rank rebuilds after the gather."""
+
+    def __init__(self, world: int, rank: int, batch: int, positions: int, num_rows: int, l1: int, head: int, tail_lo: int,
+                 tail: int, device):
+        L = load()
+        self.world, self.rank, self.batch, self.positions, self.l1 = world, rank, batch, positions, l1
+        self.head, self.tail_lo, self.tail = int(head), int(tail_lo), int(tail)
+        small = self.head + self.tail
+        self.chunk_bytes = int(L.nnue_dp_factor_chunk_bytes(batch, positions, l1, small))
+        if self.chunk_bytes <= 0 or self.chunk_bytes % 16:
+            raise NnueHipError("nnue_dp_factor_chunk_bytes: unusable shape")
+        self.chunks = torch.zeros((world, self.chunk_bytes), dtype=torch.uint8, device=device)
+        self.own = self.chunks[rank]
+        off = [int(L.nnue_dp_factor_offset(w, batch, positions, l1, small)) for w in range(4)]
+        self.d_ft = self.own[off[0]:off[0] + batch * l1 * 4].view(torch.float32).view(batch, l1)
+        self.sink = self.own[off[1]:off[1] + batch * 4].view(torch.float32)
+        rows = world * batch
+        self.g_dft = torch.empty((rows, l1), dtype=torch.float32, device=device)
+        # the global map as a FeatureMatrix: what nnue_ftm_gram_sqnorm / nnue_ftm_backward_weight_update take (no forward scratch)
+        self.g_fm = FeatureMatrix(torch.empty((rows, positions), dtype=torch.uint8, device=device),
+                                  torch.zeros((rows,), dtype=torch.int32, device=device),
+                                  torch.empty((rows,), dtype=torch.float32, device=device),
+                                  torch.empty((16,), dtype=torch.uint8, device=device), positions, num_rows)
+
+    def pack(self, fm: "FeatureMatrix", flat_grads: torch.Tensor) -> None:
+        """own chunk <- map bits + the small gradients (d_ft and sink are already there)."""
+        _call("nnue_dp_factor_pack", fm.bits.data_ptr(), flat_grads.data_ptr(), self.head, self.tail_lo, self.tail, self.batch,
+              self.positions, self.l1, self.own.data_ptr(), _stream(flat_grads))
+
+    def unpack(self, flat_grads: torch.Tensor) -> None:
+        """gathered chunks -> global factors; flat_grads' small parts <- their sum over the ranks (rank order)."""
+        _call("nnue_dp_factor_unpack", self.chunks.data_ptr(), self.world, self.batch, self.positions, self.l1, self.head, self.tail_lo,
+              self.tail, self.g_fm.bits.data_ptr(), self.g_fm.sink.data_ptr(), self.g_dft.data_ptr(), flat_grads.data_ptr(),
+              _stream(flat_grads))
 
 
 def sgd_step(params: torch.Tensor, grads: torch.Tensor, momentum_buf: Optional[torch.Tensor], lr: float,

@@ -143,6 +143,16 @@ class DataParallel:
             dist.all_gather(parts, shard.clone(), group=self.group)
 
 
+    def all_gather_chunks(self, chunks: torch.Tensor) -> None:
+        """chunks [world][n] (any dtype): row r <- rank r's row; every rank sends its own row in place."""
+        if not self.collectives:
+            return
+        if self.backend == "nccl":
+            dist.all_gather_into_tensor(chunks.view(-1), chunks[self.rank], group=self.group)
+        else:
+            dist.all_gather([chunks[r] for r in range(self.world)], chunks[self.rank].clone(), group=self.group)
+
+
 class NnueTrainer:
     """Owns the flat buffers and the activation workspace for one (batch, H, W) shape."""
 
@@ -205,6 +215,26 @@ class NnueTrainer:
         self.ft_path = lib.ft_path(self.F, self.P, self.L1, B)
         self.use_mfma, self.use_bits = self.ft_path == "mfma", self.ft_path == "bits"
         self.fm = lib.FeatureMatrix.empty(B, self.P, self.F, self.L1, self.dev) if self.use_mfma else None
+        # Data parallel with a bandwidth-sized table: the ranks all-gather the FACTORS of the table's gradient (the map as
+        # bits + d_ft, ~1.5 MB per rank at the 224x224 shape) instead of reducing the 269 MB product, and every rank runs the
+        # fused single-rank path (Gram norm, update in the product's epilogue) on the global factors: no big collective, no
+        # materialised d_W, bitwise identical replicas.  The other gradients travel in the same all-gather and are summed in
+        # rank order (lib.FactorExchange).  NNUE_DP_FACTOR_EXCHANGE=auto|1|0; auto = tables of 32 MB or more.
+        fx_mode = os.environ.get("NNUE_DP_FACTOR_EXCHANGE", "auto")
+        fx_rows = min(self.F - 1, self.P)
+        fx_off = self.layout.offsets[self.layout.names.index("input.weight")]
+        gb = B * self.dp.world
+        self.factor_exchange = (self.dp.collectives and self.use_mfma and optimizer == "sgd" and self.dp.buckets == 1 and fx_rows > 0
+                                and self.layout.names[:3] == ["visual_threshold", "conv.weight", "input.weight"]
+                                and gb * self.L1 <= (1 << 24) and ((gb + 15) // 16) * ((self.L1 + 15) // 16) <= 65536
+                                and fx_off % 4 == 0 and (fx_rows * self.L1) % 4 == 0 and fx_mode != "0"
+                                and (fx_mode == "1" or self.F * self.L1 * 4 >= (32 << 20)))
+        self.fx = None
+        if self.factor_exchange:
+            tail_lo = fx_off + fx_rows * self.L1
+            self.fx = lib.FactorExchange(self.dp.world, self.dp.rank, B, self.P, self.F, self.L1, head=fx_off, tail_lo=tail_lo,
+                                         tail=self.layout.count - tail_lo, device=self.dev)
+            self.fm.sink = self.fx.sink  # written by the binarise kernel straight into this rank's chunk
         self.bits = lib.FeatureBits.empty(B, self.P, self.F, self.L1, self.dev) if self.use_bits else None
         self.act = lib.ActList.empty(B, self.P, self.F, self.dev) if self.ft_path == "list" else None
         self.ft = torch.empty((B, self.L1), **f32)
@@ -215,7 +245,7 @@ class NnueTrainer:
         self.loss = torch.zeros((), **f32)
         self.loss_ring = torch.zeros((max(1, input_slots),), **f32)  # step_many's per-step mean losses
         self.d_logits = torch.empty((B, self.C), **f32)
-        self.d_ft = torch.empty((B, self.L1), **f32)
+        self.d_ft = self.fx.d_ft if self.fx is not None else torch.empty((B, self.L1), **f32)  # (the chunk's view: sent in place)
         self.d_conv_out = torch.empty((B, self.P), **f32)
         self.grad_norm = torch.zeros((), **f32)
         u8 = dict(dtype=torch.uint8, device=self.dev)
@@ -240,7 +270,7 @@ class NnueTrainer:
         # the norm assembled from all-gathered block partials, all-gather of the parameters.  NNUE_DP_SHARDED_UPDATE=0|1|auto
         mode = os.environ.get("NNUE_DP_SHARDED_UPDATE", "auto")
         self.sharded_update = (self.dp.collectives and optimizer == "sgd" and self.dp.buckets == 1 and mode != "0"
-                               and (mode == "1" or self.layout.count * 4 >= (64 << 20)))
+                               and not self.factor_exchange and (mode == "1" or self.layout.count * 4 >= (64 << 20)))
         if self.sharded_update:
             per = self.layout.count // self.dp.world
             self.grad_shard = torch.empty((per,), **f32)
@@ -296,7 +326,13 @@ class NnueTrainer:
         # With the fused table update ``model.input.weight.grad`` (a view of flat_grads) is never written: rows the product
         # covers stay at the zeros they were allocated with.  ``grads_materialised`` says so; callers that want the table's
         # gradient for logging or custom clipping set NNUE_FUSE_TABLE_UPDATE=0.
-        self.grads_materialised = not self.fuse_table_update
+        if self.factor_exchange:  # the same fused update, on the global factors (B * world rows)
+            self.ride_dw1 = False
+            self.sq_partial = torch.empty((int(lib.load().nnue_ftm_gram_sq_count(gb, self.L1)),), **f32)
+            self.sq_range = (fx_off, fx_off + fx_rows * self.L1)
+            self.gram = torch.zeros((lib.ftm_gram_scratch(self.fx.g_fm),), **f32)
+            self.clip_coef = torch.ones((), **f32)
+        self.grads_materialised = not (self.fuse_table_update or self.factor_exchange)
         self.d_z1 = self.ft_rider = None
         if self.ride_dw1 and self.K == 1:
             off = lib.classifier_train_dz1_offset(B, self.L1, self.L2, self.L3, self.C, True)
@@ -390,7 +426,11 @@ class NnueTrainer:
                 lib.ft_forward(p["input.weight"], p["input.bias"], self.act, out=self.ft)
             self._cls_step(19 if self.ride_dw1 else 5)  # 5: + the first-layer weight product beside d_x
         elif name == "ft_wgrad":
-            if self.fuse_table_update:
+            if self.factor_exchange:
+                # this rank's share of the rows the product does not cover; they travel with the small gradients, the
+                # norm and the product wait for the global factors (_exchange_and_update)
+                lib.ftm_backward_tail_rows(self.d_ft, self.fm, g["input.weight"], g["input.bias"])
+            elif self.fuse_table_update:
                 # rows the product does not cover (bias, clamp-sink row, unreachable rows) + the Gram form of the norm;
                 # the product itself is part of the update (_update)
                 lib.ftm_backward_tail_rows(self.d_ft, self.fm, g["input.weight"], g["input.bias"])
@@ -411,7 +451,7 @@ class NnueTrainer:
             if not self.ride_dw1:  # else the small gradients already rode in the d_x launch of "forward"
                 self._cls_step(6)
         elif name == "tail":
-            if self.use_mfma and self.merge_backward and not self.fuse_table_update:
+            if self.use_mfma and self.merge_backward and not self.fuse_table_update and not self.factor_exchange:
                 pass  # d_conv_out came out of the merged launch in "ft_wgrad"
             elif self.use_mfma:
                 lib.ftm_backward_values(self.d_ft, p["input.weight"], self.fm, dst=self.d_conv_out)
@@ -457,6 +497,20 @@ class NnueTrainer:
     def _exchange_and_update(self, first: bool, grad_scale: Optional[float] = None) -> None:
         """Everything after the local kernels of a data-parallel step, as launches on the current stream: the gradient
         exchange and the optimizer.  Capturable (no host synchronisation)."""
+        if self.factor_exchange:
+            fx, scale = self.fx, (self.dp.grad_scale if grad_scale is None else grad_scale)
+            fx.pack(self.fm, self.flat_grads)
+            self.dp.all_gather_chunks(fx.chunks)  # the step's one collective
+            fx.unpack(self.flat_grads)
+            lib.ftm_gram_sqnorm(fx.g_fm, fx.g_dft, self.gram, self.sq_partial)
+            lib.sgd_step(self.flat_params, self.flat_grads, self.flat_momentum, self.lr, self.momentum, self.weight_decay,
+                         self.max_grad_norm, scale, first, self.grad_norm, self.sgd_scratch, ext=(self.sq_partial, *self.sq_range),
+                         coef_out=self.clip_coef, ext_applied_elsewhere=True)
+            lo, hi = self.sq_range
+            mom = self.flat_momentum[lo:hi] if self.flat_momentum is not None else None
+            lib.ftm_backward_weight_update(fx.g_dft, fx.g_fm, self.p["input.weight"], mom, self.clip_coef, self.lr, self.momentum,
+                                           self.weight_decay, scale, first)
+            return
         if not self.sharded_update:
             self.dp.allreduce_sum(self.flat_grads, async_op=False)
             self._update(first, grad_scale)
@@ -532,6 +586,8 @@ class NnueTrainer:
                     self._segment(name)
                 self._plan_seg[name] = list(calls)
             self._plan_local = [c for name in self.SEGMENTS for c in self._plan_seg[name]]
+        if self._plan_update is None and (self.sharded_update or self.factor_exchange):
+            self._plan_update_first = self._plan_update = []  # these modes issue exchange + update themselves (_exchange_and_update)
         if self._plan_update is None:
             live = [self.flat_params, self.flat_grads, self.grad_norm] + self._optimizer_buffers()
             keep = [t.clone() for t in live]  # recording executes the updates: put everything back afterwards
@@ -607,7 +663,7 @@ class NnueTrainer:
                 if (slot, part) not in self._g_local:
                     self._g_local[(slot, part)] = self._capture(
                         lambda st, part=part: self._run_local(slot, part, st, branch=self.branch))
-            if self._g_update is None:
+            if self._g_update is None and upd:
                 self._g_update = self._capture(lambda st: lib.run_plan(upd, st.cuda_stream))
 
         def run(part):
@@ -645,9 +701,10 @@ class NnueTrainer:
             return self.loss
         if not self.dp.collectives:
             run("all")
-        elif self.sharded_update:
+        elif self.sharded_update or self.factor_exchange:
             run("all")
-            self._exchange_and_update(first, grad_scale=self.dp.grad_scale * ragged if ragged is not None else None)
+            with lib.time_calls(timers):
+                self._exchange_and_update(first, grad_scale=self.dp.grad_scale * ragged if ragged is not None else None)
             self.steps_done += 1
             return self.loss * ragged if ragged is not None else self.loss
         elif not two_buckets:

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_header_cites_the_reference_for_each_entry_point():
     for n in declared_functions():
-        if n in ("nnue_hip_abi_version", "nnue_hip_last_error", "nnue_ftm_uses_bf16") or n.endswith(("_scratch", "_scratch_bucketed", "_supported", "_list_tiles", "_offset", "_chunks", "_count")):  # size / capability queries
+        if n in ("nnue_hip_abi_version", "nnue_hip_last_error", "nnue_ftm_uses_bf16") or n.endswith(("_scratch", "_scratch_bucketed", "_supported", "_list_tiles", "_offset", "_chunks", "_count", "_bytes")):  # size / capability queries
             continue
         m = re.search(r"/\*((?:(?!/\*).)*?)\*/\s*(?:int64_t[^;]*;\s*)*int\s+" + n + r"\(", HEADER, flags=re.S)
         assert m, f"{n}: no doc comment"

@@ -56,6 +56,7 @@ def _worker(rank, port, out_dir, world, backend, use_graph, env, short_last):
         tr = NnueTrainer(model, per, (32, 32), use_graph=use_graph, input_slots=2, **OPT)
         assert tr.dp.world == world and tr.bucket_split == 8 + 8 * 27
         assert tr.sharded_update == (env.get("NNUE_DP_SHARDED_UPDATE") == "1")
+        assert tr.factor_exchange == (env.get("NNUE_DP_FACTOR_EXCHANGE") == "1") and tr.grads_materialised != tr.factor_exchange
         assert tr.capture_collectives == (backend == "nccl" and use_graph and env.get("NNUE_DP_CAPTURE", "1") != "0")
         sl = tr.dp.shard(GLOBAL_BATCH)
         losses = []
@@ -137,13 +138,24 @@ def test_two_ranks_with_the_sharded_update(tmp_path, use_graph):
     _run(tmp_path, 2, "gloo", use_graph, {"NNUE_DP_SHARDED_UPDATE": "1"})
 
 
+@pytest.mark.parametrize("use_graph", (False, True))
+def test_two_ranks_exchanging_the_gradient_factors(tmp_path, use_graph):
+    """The table's gradient is never reduced: bit map + d_ft are all-gathered, every rank runs the Gram norm and the update in
+    the product's epilogue on the global batch, the small gradients are summed from the same gathered chunks."""
+    _run(tmp_path, 2, "gloo", use_graph, {"NNUE_DP_FACTOR_EXCHANGE": "1"})
+
+
+def test_two_ranks_exchanging_factors_with_a_short_last_batch(tmp_path):
+    _run(tmp_path, 2, "gloo", True, {"NNUE_DP_FACTOR_EXCHANGE": "1"}, short_last=True)
+
+
 @pytest.mark.parametrize("sharded", ("0", "1"))
 def test_two_ranks_with_a_short_last_batch(tmp_path, sharded):
     """25 real samples in a global batch of 32: rank 0 holds 16, rank 1 nine; the mean is over the 25."""
     _run(tmp_path, 2, "gloo", True, {"NNUE_DP_SHARDED_UPDATE": sharded}, short_last=True)
 
 
-@pytest.mark.parametrize("env", ({}, {"NNUE_DP_SHARDED_UPDATE": "1"}, {"NNUE_DP_CAPTURE": "0"}))
+@pytest.mark.parametrize("env", ({}, {"NNUE_DP_SHARDED_UPDATE": "1"}, {"NNUE_DP_CAPTURE": "0"}, {"NNUE_DP_FACTOR_EXCHANGE": "1"}))
 def test_one_rank_over_rccl_with_the_collective_inside_the_graph(tmp_path, env):
     """backend "nccl" (= RCCL) with a single rank, collectives forced on: the all-reduce (or reduce-scatter / all-gather
     pair) is captured into the step's hipGraph and replayed; the trajectory is the plain single-rank one."""
@@ -159,10 +171,11 @@ def test_two_ranks_step_many_falls_back_to_single_steps_over_gloo(tmp_path):
 def test_one_rank_over_rccl_two_steps_in_one_graph(tmp_path):
     """step_many under collectives: two consecutive steps, each with its all-reduce, captured and replayed as one hipGraph."""
     _run(tmp_path, 1, "nccl", True, {"NNUE_DP_FORCE_COLLECTIVES": "1", "TEST_STEP_MANY": "1"})
+    _run(tmp_path, 1, "nccl", True, {"NNUE_DP_FORCE_COLLECTIVES": "1", "TEST_STEP_MANY": "1", "NNUE_DP_FACTOR_EXCHANGE": "1"})
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI between ranks)")
-@pytest.mark.parametrize("env", ({}, {"NNUE_DP_SHARDED_UPDATE": "1"}, {"NNUE_DP_CAPTURE": "0"}))
+@pytest.mark.parametrize("env", ({}, {"NNUE_DP_SHARDED_UPDATE": "1"}, {"NNUE_DP_CAPTURE": "0"}, {"NNUE_DP_FACTOR_EXCHANGE": "1"}))
 def test_two_ranks_over_rccl(tmp_path, env):
     _run(tmp_path, 2, "nccl", True, env)
     _run(tmp_path, 2, "nccl", True, env, short_last=True)

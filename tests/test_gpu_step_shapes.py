@@ -78,8 +78,32 @@ def clean_batch(cfg, params, stride, gen, margin=1e-5, gate_margin=2e-5):
     return images, torch.randint(0, cfg["classes"], (b,), generator=gen)
 
 
+@pytest.fixture
+def one_rank_rccl(monkeypatch):
+    """A one-rank RCCL process group with the collectives forced on (NNUE_DP_FORCE_COLLECTIVES): the data-parallel code path
+    -- here the factor exchange of the 224x224 shape -- with everything a second rank would add except wire time."""
+    import socket
+    import torch.distributed as dist
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", str(port))
+    monkeypatch.setenv("NNUE_DP_FORCE_COLLECTIVES", "1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+    yield
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
+
+
+def test_three_steps_at_the_224_shape_through_the_factor_exchange(one_rank_rccl):
+    """BASELINE configs[3]'s shape under data parallel: bit map + d_ft all-gathered (captured in the step graph), Gram norm
+    and update on the gathered factors -- against the same oracle steps as the single-rank path."""
+    test_three_steps_at_the_baseline_shape_follow_the_oracle("c4", expect_factor_exchange=True)
+
+
 @pytest.mark.parametrize("name", ("c2", "c3", "c4", "c3k8", "c3k8_spread"))
-def test_three_steps_at_the_baseline_shape_follow_the_oracle(name):
+def test_three_steps_at_the_baseline_shape_follow_the_oracle(name, expect_factor_exchange=False):
     cfg = SHAPES[name]
     torch.manual_seed(0)
     model = nnue.NNUE(nnue.GridFeatureSet(cfg["grid"], cfg["fps"]), cfg["l1"], cfg["l2"], cfg["l3"],
@@ -97,6 +121,7 @@ def test_three_steps_at_the_baseline_shape_follow_the_oracle(name):
     if os.environ.get("NNUE_FT_PATH", "auto") not in ("auto", "mfma"):
         pytest.skip("another FeatureTransformer kernel family is forced (NNUE_FT_PATH)")
     assert tr.ft_path == "mfma" and tr.use_graph
+    assert tr.factor_exchange == expect_factor_exchange and (not expect_factor_exchange or tr.capture_collectives)
     if name in ("c2", "c3"):  # every default fusion is on (a knob set to its non-default value switches its own off)
         on = lambda k: os.environ.get(k, "1") != "0"  # noqa: E731
         merged = os.environ.get("NNUE_FTM_SPLIT_BACKWARD", "0") != "1"

@@ -22,7 +22,7 @@ python tools/pmc_summary.py c2 $O/pmc_c2_FETCH_SIZE $O/pmc_c2_WRITE_SIZE $O/pmc_
 mkdir -p $R/profiles; for w in c2 c3 c4; do cp $O/kernel_stats_$w.csv $R/profiles/${TAG}_kernel_stats_$w.csv 2>/dev/null; done; cp $O/pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json 2>/dev/null
 for w in c1 c2 c3 c3k1; do python bench.py --workload $w --steps 300 --warmup 30 > $O/bench_$w.json 2> $O/bench_$w.err || echo "bench $w failed"; done
 python bench.py --workload c4 --steps 100 --warmup 10 > $O/bench_c4.json 2> $O/bench_c4.err || echo "bench c4 failed"
-python bench.py --workload c3 --spread --steps 300 --warmup 30 --no-cpu-baseline > $O/bench_c3_spread.json 2> $O/bench_c3_spread.err
+python bench.py --workload c3 --no-spread --steps 300 --warmup 30 --no-cpu-baseline --no-gather-compare > $O/bench_c3_nospread.json 2> $O/bench_c3_nospread.err
 # one graph launch per step (round-1 form) and the driver's own invocation
 python bench.py --workload c2 --steps 300 --warmup 30 --steps-per-graph 1 --no-cpu-baseline --no-gather-compare > $O/bench_c2_spg1.json 2> $O/bench_c2_spg1.err
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_c2_driver_form.json 2> $O/bench_c2_driver_form.err

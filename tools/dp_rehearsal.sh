@@ -9,7 +9,10 @@ NNUE_DP_FORCE_COLLECTIVES=1 $TR --master-port 29511 bench.py --gpus 1 --workload
 NNUE_DP_FORCE_COLLECTIVES=1 $TR --master-port 29515 bench.py --gpus 1 --workload c2 $B --steps-per-graph 1 > $O/c2_dp1_captured_spg1.json 2>$O/err6
 NNUE_DP_FORCE_COLLECTIVES=1 NNUE_DP_CAPTURE=0 $TR --master-port 29512 bench.py --gpus 1 --workload c2 $B > $O/c2_dp1_eager.json 2>$O/err3
 C4="--workload c4 --steps 100 --warmup 10 --no-cpu-baseline --no-gather-compare"
-NNUE_DP_FORCE_COLLECTIVES=1 $TR --master-port 29513 bench.py --gpus 1 $C4 > $O/c4_dp1_sharded.json 2>$O/err4
-NNUE_DP_FORCE_COLLECTIVES=1 NNUE_DP_SHARDED_UPDATE=0 $TR --master-port 29514 bench.py --gpus 1 $C4 > $O/c4_dp1_allreduce.json 2>$O/err5
-for f in c2_single c2_dp1_captured c2_dp1_captured_spg1 c2_dp1_eager c4_dp1_sharded c4_dp1_allreduce; do echo $f; cut -c1-260 $O/$f.json; echo; done
-for e in $O/err2 $O/err4; do tail -n 2 $e; done
+python bench.py $C4 > $O/c4_single.json 2>$O/err7
+# default under collectives at this shape: the gradient's FACTORS are all-gathered, fused update on the global batch
+NNUE_DP_FORCE_COLLECTIVES=1 $TR --master-port 29516 bench.py --gpus 1 $C4 > $O/c4_dp1_factors.json 2>$O/err8
+NNUE_DP_FORCE_COLLECTIVES=1 NNUE_DP_FACTOR_EXCHANGE=0 $TR --master-port 29513 bench.py --gpus 1 $C4 > $O/c4_dp1_sharded.json 2>$O/err4
+NNUE_DP_FORCE_COLLECTIVES=1 NNUE_DP_FACTOR_EXCHANGE=0 NNUE_DP_SHARDED_UPDATE=0 $TR --master-port 29514 bench.py --gpus 1 $C4 > $O/c4_dp1_allreduce.json 2>$O/err5
+for f in c2_single c2_dp1_captured c2_dp1_captured_spg1 c2_dp1_eager c4_single c4_dp1_factors c4_dp1_sharded c4_dp1_allreduce; do echo $f; cut -c1-260 $O/$f.json; echo; done
+for e in $O/err2 $O/err8 $O/err4; do tail -n 2 $e; done
