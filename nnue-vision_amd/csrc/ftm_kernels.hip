@@ -995,7 +995,9 @@ __device__ __forceinline__ void split8(const u32x4& v0, const u32x4& v1, u32x4& 
   }
 }
 
-template <int BM, int BN, class Epi, int KT = kBf6K>
+// ABL: timing-only ablations for tools/debug (results are WRONG unless 0): 1 no split of A (raw words stored), 2 no split at
+// all, 3 no MFMAs (fragments still read), 4 no staging (no split, no LDS stores), 5 no global loads
+template <int BM, int BN, class Epi, int KT = kBf6K, int ABL = 0>
 __device__ __forceinline__ void gemm_tile_bf6(unsigned char* __restrict__ smem, const Mat& ma, const Mat& mb, const Epi& epi, int M, int N,
                                               int k_lo, int k_hi, int tiles_n, int tile, int ks) {
   static_assert((BM == 32 || BM == 64 || BM == 128) && (BN == 64 || BN == 128), "tile shapes");
@@ -1017,6 +1019,9 @@ __device__ __forceinline__ void gemm_tile_bf6(unsigned char* __restrict__ smem, 
   const bool stream_b = mb.bytes > (64u << 20);        // uniform: a table larger than the caches is read non-temporally
   u32x4 ra[GA][2], rb[GB][2];
   auto fetch = [&](int k0) {
+    if constexpr (ABL == 5) {
+      if (k0 != k_lo) return;
+    }
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
       const int g = tid + 256 * i, row = g / RUNS, k = k0 + (g % RUNS) * 8;
@@ -1038,11 +1043,13 @@ __device__ __forceinline__ void gemm_tile_bf6(unsigned char* __restrict__ smem, 
     }
   };
   auto stage = [&]() {
+    if constexpr (ABL == 4) return;
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
       const int g = tid + 256 * i, row = g / RUNS, c = g % RUNS;
       u32x4 hi, mid, lo;
-      split8(ra[i][0], ra[i][1], hi, mid, lo);
+      if constexpr (ABL == 1 || ABL == 2) { hi = ra[i][0]; mid = ra[i][1]; lo = ra[i][0] ^ ra[i][1]; }
+      else split8(ra[i][0], ra[i][1], hi, mid, lo);
       *reinterpret_cast<u32x4*>(As + bf6_img<KT>(row, c)) = hi;
       *reinterpret_cast<u32x4*>(As + PA + bf6_img<KT>(row, c)) = mid;
       *reinterpret_cast<u32x4*>(As + 2 * PA + bf6_img<KT>(row, c)) = lo;
@@ -1051,7 +1058,8 @@ __device__ __forceinline__ void gemm_tile_bf6(unsigned char* __restrict__ smem, 
     for (int i = 0; i < GB; ++i) {
       const int g = tid + 256 * i, row = g / RUNS, c = g % RUNS;
       u32x4 hi, mid, lo;
-      split8(rb[i][0], rb[i][1], hi, mid, lo);
+      if constexpr (ABL == 2) { hi = rb[i][0]; mid = rb[i][1]; lo = rb[i][0] ^ rb[i][1]; }
+      else split8(rb[i][0], rb[i][1], hi, mid, lo);
       *reinterpret_cast<u32x4*>(Bs + bf6_img<KT>(row, c)) = hi;
       *reinterpret_cast<u32x4*>(Bs + PB + bf6_img<KT>(row, c)) = mid;
       *reinterpret_cast<u32x4*>(Bs + 2 * PB + bf6_img<KT>(row, c)) = lo;
@@ -1076,12 +1084,21 @@ __device__ __forceinline__ void gemm_tile_bf6(unsigned char* __restrict__ smem, 
       }
       // smallest terms first (plane 0 = hi, 1 = mid, 2 = lo); consecutive MFMAs go to different accumulators
       constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+      if constexpr (ABL == 3) {  // keep the fragment reads alive without the matrix unit
+#pragma unroll
+        for (int s6 = 0; s6 < 6; ++s6)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int t = 0; t < TN; ++t) acc[i][t][0] += (float)a[pa[s6]][i][0] + (float)b[pb[s6]][t][0];
+      } else {
 #pragma unroll
       for (int s6 = 0; s6 < 6; ++s6)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int t = 0; t < TN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa[s6]][i], b[pb[s6]][t], acc[i][t], 0, 0, 0);
+      }
     }
   };
   fetch(k_lo);
@@ -1095,10 +1112,10 @@ __device__ __forceinline__ void gemm_tile_bf6(unsigned char* __restrict__ smem, 
   store_tile<BM, BN, Epi>(reinterpret_cast<float*>(smem), epi, acc, M, N, m_base, n_base, m0, n0, tile, ks);
 }
 
-template <int BM, int BN, class Epi, int KT>
+template <int BM, int BN, class Epi, int KT, int ABL = 0>
 __global__ __launch_bounds__(256) void ftm_gemm_bf6_kernel(Mat ma, Mat mb, Epi epi, int M, int N, int K, int tiles_n) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[gemm_bf6_lds_bytes<BM, BN, KT>()];
-  gemm_tile_bf6<BM, BN, Epi, KT>(smem, ma, mb, epi, M, N, 0, K, tiles_n, blockIdx.x, 0);
+  gemm_tile_bf6<BM, BN, Epi, KT, ABL>(smem, ma, mb, epi, M, N, 0, K, tiles_n, blockIdx.x, 0);
 }
 
 template <int BM, int BN, bool AKC, class Epi>
@@ -1792,6 +1809,10 @@ extern "C" int nnue_ftm_backward_values(const uint8_t* bits, const float* d_out,
     // 115 us with K tiles of 64 (72 KB, two per CU) and 147 us on the f32 MFMA at the 224x224 shape
     static const int kt = env_int("NNUE_FTM_BF6_KT", 32);  // developer knob
     const dim3 grid((unsigned)(s.tiles_m * s.tiles_n));
+    static const int abl = env_int("NNUE_FTM_BF6_ABL", 0);  // timing-only ablations (wrong results), tools/debug
+#define NNUE_ABL(N) if (abl == N) { hipLaunchKernelGGL((ftm_gemm_bf6_kernel<128, 64, ValEpi, 32, N>), grid, dim3(256), 0, st, ma, mb, epi, B, P, L1, s.tiles_n); return nnue_launch_status("nnue_ftm_backward_values"); }
+    NNUE_ABL(1) NNUE_ABL(2) NNUE_ABL(3) NNUE_ABL(4) NNUE_ABL(5)
+#undef NNUE_ABL
     if (kt == 64) hipLaunchKernelGGL((ftm_gemm_bf6_kernel<128, 64, ValEpi, 64>), grid, dim3(256), 0, st, ma, mb, epi, B, P, L1, s.tiles_n);
     else hipLaunchKernelGGL((ftm_gemm_bf6_kernel<128, 64, ValEpi, 32>), grid, dim3(256), 0, st, ma, mb, epi, B, P, L1, s.tiles_n);
     return nnue_launch_status("nnue_ftm_backward_values");
