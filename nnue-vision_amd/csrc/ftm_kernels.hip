@@ -1813,6 +1813,12 @@ extern "C" int nnue_ftm_backward_values(const uint8_t* bits, const float* d_out,
 #define NNUE_ABL(N) if (abl == N) { hipLaunchKernelGGL((ftm_gemm_bf6_kernel<128, 64, ValEpi, 32, N>), grid, dim3(256), 0, st, ma, mb, epi, B, P, L1, s.tiles_n); return nnue_launch_status("nnue_ftm_backward_values"); }
     NNUE_ABL(1) NNUE_ABL(2) NNUE_ABL(3) NNUE_ABL(4) NNUE_ABL(5)
 #undef NNUE_ABL
+    static const int bn = env_int("NNUE_FTM_BF6_BN", 64);  // developer knob: 128-column tiles stage d_out half as often
+    if (bn == 128) {
+      const int tn = (P + 127) / 128;
+      hipLaunchKernelGGL((ftm_gemm_bf6_kernel<128, 128, ValEpi, 32>), dim3((unsigned)(s.tiles_m * tn)), dim3(256), 0, st, ma, mb, epi, B, P, L1, tn);
+      return nnue_launch_status("nnue_ftm_backward_values");
+    }
     if (kt == 64) hipLaunchKernelGGL((ftm_gemm_bf6_kernel<128, 64, ValEpi, 64>), grid, dim3(256), 0, st, ma, mb, epi, B, P, L1, s.tiles_n);
     else hipLaunchKernelGGL((ftm_gemm_bf6_kernel<128, 64, ValEpi, 32>), grid, dim3(256), 0, st, ma, mb, epi, B, P, L1, s.tiles_n);
     return nnue_launch_status("nnue_ftm_backward_values");

@@ -24,6 +24,8 @@ from pathlib import Path
 from types import ModuleType
 from typing import Callable, Dict, Iterable, List, Optional
 
+import os
+
 import torch
 
 from . import lib
@@ -105,6 +107,7 @@ def run_training(config, train_loader: Iterable, val_loader: Iterable, test_load
             for images, labels in train_loader:
                 trainer.step(images.to(device, non_blocking=True), labels.to(device, non_blocking=True).long())
                 result.steps += 1
+        trainer = _density_check(trainer, log)
         model.eval()
         train_loss, train_metrics = evaluate.evaluate_model(model, train_loader, None, device)
         val_loss, val_metrics = evaluate.evaluate_model(model, val_loader, None, device)
@@ -131,6 +134,33 @@ def run_training(config, train_loader: Iterable, val_loader: Iterable, test_load
         test_loss, test_metrics = evaluate.evaluate_model(model, test_loader, None, device)
         result.test = {"test/f1": test_metrics["f1"], "test/loss": test_loss}
     return result
+
+
+# Active-feature density below which the gather kernels beat the dense products, by table size (measured on MI355X with
+# `bench.py --density D`, which times both forms in one process; profiles/r03*_dens_*.json).  The thresholds
+# are learnable (nnue.py:505-507), so the density is a property of the run, not of the shape: the check runs once per epoch on
+# the counts the last step left, costs one read-back, and rebuilds the trainer (plans and graphs) only when it switches.
+# NNUE_FT_DENSITY_SWITCH=0 disables it; a forced NNUE_FT_PATH is respected.
+GATHER_BELOW_DENSITY = {"cache_resident_table": 0.0, "streamed_table": 0.0}  # 0 = the product form won at every measured density
+
+
+def _density_check(trainer, log=print):
+    if os.environ.get("NNUE_FT_DENSITY_SWITCH", "1") == "0" or os.environ.get("NNUE_FT_PATH", "auto") != "auto":
+        return trainer
+    if trainer.ft_path not in ("mfma", "bits") or not lib.ftb_supported(trainer.L1):
+        return trainer
+    density = trainer.active_stats()[0] / max(1, trainer.P)
+    regime = "streamed_table" if trainer.F * trainer.L1 * 4 >= (200 << 20) else "cache_resident_table"
+    want = "bits" if density < GATHER_BELOW_DENSITY[regime] else "mfma"
+    if trainer.dp.world > 1:  # the same decision on every rank: take rank 0's
+        import torch.distributed as dist
+        flag = torch.tensor([1 if want == "bits" else 0], dtype=torch.int32, device=trainer.dev if trainer.dp.backend == "nccl" else "cpu")
+        dist.broadcast(flag, src=dist.get_global_rank(trainer.dp.group, 0) if trainer.dp.group is not None else 0, group=trainer.dp.group)
+        want = "bits" if int(flag.item()) else "mfma"
+    if want == trainer.ft_path or (want == "mfma" and lib.ft_path(trainer.F, trainer.P, trainer.L1, trainer.B) != "mfma"):
+        return trainer
+    log(f"active-feature density {density:.4f}: FeatureTransformer kernels {trainer.ft_path} -> {want}")
+    return trainer.rebuilt(want)
 
 
 def train_model(config, model_type: str = "nnue", train_loader=None, val_loader=None, test_loader=None, **kwargs) -> int:

@@ -784,6 +784,30 @@ class NnueTrainer:
         self.steps_done += len(slots)
         return ring[:len(slots)]
 
+    def rebuilt(self, ft_path: str) -> "NnueTrainer":
+        """A trainer for the same model, shapes, hyper-parameters and optimizer state that uses another FeatureTransformer
+        kernel family (``"mfma"`` | ``"bits"`` | ``"list"`` | ``"auto"``, as NNUE_FT_PATH) -- the train loop's density check
+        calls this at an epoch boundary when the learnable thresholds have moved the active-feature density across the
+        measured crossover of the dense-product and gather forms.  This trainer must not be used afterwards (the module's
+        parameters become views of the new trainer's buffers)."""
+        torch.cuda.synchronize(self.dev)
+        old = os.environ.get("NNUE_FT_PATH")
+        os.environ["NNUE_FT_PATH"] = ft_path
+        try:
+            new = NnueTrainer(self.model, self.B, (self.H, self.W), group=self.dp.group, use_graph=self.use_graph,
+                              input_slots=len(self.inputs), optimizer=self.optimizer, betas=self.betas, eps=self.eps, **self._hyper)
+        finally:
+            if old is None:
+                os.environ.pop("NNUE_FT_PATH", None)
+            else:
+                os.environ["NNUE_FT_PATH"] = old
+        if self.sharded_update and self.flat_momentum is not None and self.dp.world > 1 and self.steps_done > 0:
+            self.dp.all_gather(self.flat_momentum, self.dp.shard_of(self.flat_momentum))
+        for src, dst in zip(self._optimizer_buffers(), new._optimizer_buffers()):
+            dst.copy_(src)
+        new.steps_done = self.steps_done
+        return new
+
     def optimizer_state_dict(self) -> dict:
         """The optimizer state in torch.optim's own state_dict format (SGD momentum buffers, or Adam's step /
         exp_avg / exp_avg_sq), indexed like ``model.parameters()`` -- what checkpoint_manager.py:45-51 stores and

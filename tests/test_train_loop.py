@@ -192,3 +192,39 @@ def test_train_model_with_bucketed_layer_stacks(tmp_path):
     assert model.num_ls_buckets == 4
     serialize.serialize_model(model, tmp_path / "k4.nnue")
     assert (tmp_path / "k4.nnue").stat().st_size == orc.nnue_file_size(800, 8, 256, 32, 16, 10, buckets=4)
+
+
+@pytest.mark.gpu
+def test_density_check_switches_the_kernel_family_and_keeps_the_trajectory(monkeypatch):
+    """The epoch-end density check (train_loop._density_check): below the measured crossover the trainer is rebuilt on the
+    gather kernels, optimizer state and step count carried over; the steps that follow equal those of a trainer that never
+    switched (same arithmetic, another summation order)."""
+    from nnue_hip.trainer import NnueTrainer
+    opt = dict(lr=0.01, momentum=0.9, weight_decay=2e-4, max_grad_norm=1.0)
+    gen = torch.Generator().manual_seed(3)
+    batches = [(torch.randn(16, 3, 32, 32, generator=gen).cuda(), torch.randint(0, 10, (16,), generator=gen).cuda()) for _ in range(4)]
+
+    def fresh():
+        torch.manual_seed(0)
+        m = nnue.NNUE(nnue.GridFeatureSet(10, 8), 256, 32, 16, num_classes=10).cuda()
+        return m, NnueTrainer(m, 16, (32, 32), **opt)
+
+    m_a, tr_a = fresh()
+    m_b, tr_b = fresh()
+    assert tr_a.ft_path == "mfma"
+    for x, y in batches[:2]:
+        tr_a.step(x, y)
+        tr_b.step(x, y)
+    logs = []
+    assert train_loop._density_check(tr_a, logs.append) is tr_a and not logs  # shipped thresholds: the product form stays
+    monkeypatch.setitem(train_loop.GATHER_BELOW_DENSITY, "cache_resident_table", 1.0)
+    tr_c = train_loop._density_check(tr_a, logs.append)
+    assert tr_c is not tr_a and tr_c.ft_path == "bits" and tr_c.steps_done == 2 and "mfma -> bits" in logs[0]
+    assert torch.equal(tr_c.flat_momentum, tr_a.flat_momentum) and torch.equal(tr_c.flat_params, tr_b.flat_params)
+    for x, y in batches[2:]:
+        la, lb = tr_c.step(x, y), tr_b.step(x, y)
+        assert abs(float(la) - float(lb)) <= 1e-4 * max(1.0, abs(float(lb)))
+    for k in tr_b.p:
+        assert_close_grad(tr_c.p[k], tr_b.p[k], k, rtol=2e-4)
+    monkeypatch.setenv("NNUE_FT_DENSITY_SWITCH", "0")
+    assert train_loop._density_check(tr_b, logs.append) is tr_b
