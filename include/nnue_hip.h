@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 26
+#define NNUE_HIP_ABI_VERSION 27
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -241,6 +241,14 @@ int nnue_ftm_backward_weight(const uint8_t* bits, const float* sink, const float
  *   d_conv_out[b,p] = active(b,p) ? < d_out[b,:], weight[min(p,F-1),:] > : 0     for every p < P */
 int nnue_ftm_backward_values(const uint8_t* bits, const float* d_out, const float* weight,
                              int B, int F, int P, int L1, float* d_conv_out, nnue_stream_t stream);
+/* nnue_ftm_backward_values with a workspace (same result contract: autograd of nnue.py:702-708 and :628-633 -- the gradient
+ * reaches the map at active positions only).  For big maps the workspace lets d_out be split ONCE per launch into its three
+ * bf16 planes, staged by LDS-DMA, while the table's fragments go straight to registers (csrc/ftv_kernels.hip);
+ * nnue_ftm_backward_values_scratch returns the bytes needed (0: this shape runs the workspace-free kernels, scratch may be
+ * NULL).  Too little workspace for a shape that needs one: NNUE_E_SCRATCH. */
+int64_t nnue_ftm_backward_values_scratch(int B, int F, int P, int L1);
+int nnue_ftm_backward_values_ws(const uint8_t* bits, const float* d_out, const float* weight, int B, int F, int P, int L1,
+                                float* d_conv_out, void* scratch, int64_t scratch_bytes, nnue_stream_t stream);
 
 int nnue_ftm_backward_cw_supported(int B, int F, int P, int L1, int L2); /* shapes whose nnue_ftm_backward takes d_w1 */
 int64_t nnue_ftm_backward_sq_count(int B, int F, int P, int L1); /* floats nnue_ftm_backward's sq_partial receives; 0: none */

@@ -12,7 +12,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent
 ROOT = CSRC.parent.parent
 OUT = CSRC.parent / "nnue_hip" / "libnnue_hip.so"
-SOURCES = ["abi.cpp", "ft_kernels.hip", "ftb_kernels.hip", "ftm_kernels.hip", "feature_kernels.hip", "classifier_kernels.hip", "optim_kernels.hip", "input_kernels.hip", "engine_kernels.hip", "exchange_kernels.hip"]
+SOURCES = ["abi.cpp", "ft_kernels.hip", "ftb_kernels.hip", "ftm_kernels.hip", "feature_kernels.hip", "classifier_kernels.hip", "optim_kernels.hip", "input_kernels.hip", "engine_kernels.hip", "exchange_kernels.hip", "ftv_kernels.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result",
          "-fno-gpu-rdc", "-x", "hip", f"-I{ROOT / 'include'}", f"-I{CSRC}"]
 OBJ = CSRC / "build"  # per-source objects (git-ignored): only changed sources are recompiled, in parallel

@@ -22,6 +22,7 @@
 // block; MFMA step t takes element t), which a sum does not care about.  The next K tile's global loads are
 // issued right after the barrier that publishes the current one and stay in flight during its MFMAs.
 #include "common.h"
+#include "ftv_kernels.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -1825,6 +1826,27 @@ extern "C" int nnue_ftm_backward_values(const uint8_t* bits, const float* d_out,
   }
   launch<true, true>(st, s, ma, mb, epi, B, P, L1);
   return nnue_launch_status("nnue_ftm_backward_values");
+}
+
+// The same value gradient with a workspace: big maps take ftv_kernels.hip (d_out split once into bf16 planes in the
+// workspace and staged by LDS-DMA, table fragments straight into registers); every other shape, or a call without enough
+// workspace for it, runs nnue_ftm_backward_values unchanged.
+extern "C" int64_t nnue_ftm_backward_values_scratch(int B, int F, int P, int L1) {
+  if (!nnue_ftm_supported(F, P, L1) || !shape_ok(B, F, P, L1)) return 0;
+  return (values_bf6(B, P, L1) && ftv_supported(B, F, P, L1)) ? ftv_scratch_bytes(B, L1) : 0;
+}
+
+extern "C" int nnue_ftm_backward_values_ws(const uint8_t* bits, const float* d_out, const float* weight, int B, int F, int P, int L1,
+                                           float* d_conv_out, void* scratch, int64_t scratch_bytes, nnue_stream_t stream) {
+  const int64_t need = nnue_ftm_backward_values_scratch(B, F, P, L1);
+  if (need == 0) return nnue_ftm_backward_values(bits, d_out, weight, B, F, P, L1, d_conv_out, stream);
+  NNUE_REQUIRE(bits && d_out && weight && d_conv_out, NNUE_E_ARG, "nnue_ftm_backward_values_ws: null pointer");
+  NNUE_REQUIRE(scratch && scratch_bytes >= need, NNUE_E_SCRATCH, "nnue_ftm_backward_values_ws: workspace of %lld bytes needed, %lld given",
+               (long long)need, (long long)scratch_bytes);
+  NNUE_REQUIRE(nnue_aligned16(d_out) && nnue_aligned16(weight) && nnue_aligned16(scratch), NNUE_E_ARG,
+               "nnue_ftm_backward_values_ws: pointers must be 16-byte aligned");
+  ftv_launch(bits, d_out, weight, B, F, P, L1, d_conv_out, scratch, static_cast<hipStream_t>(stream));
+  return nnue_launch_status("nnue_ftm_backward_values_ws");
 }
 
 // Both gradients of the binary-map FeatureTransformer in one launch (see ftm_backward_kernel); falls back to the two

@@ -1,0 +1,238 @@
+// FeatureTransformer value gradient for big maps (the 224x224 shape: 65 536 positions, batch 128):
+//     d_conv_out[b][p] = bit[b][p] * sum_k d_out[b][k] * W[min(p, F-1)][k]         (autograd of nnue.py:702-708, :628-633)
+// i.e. C[M = B][N = P] = D[M][K = L1] * W^T with W streamed from HBM exactly once (268 MB) and D (0.5 MB) shared by
+// every workgroup.  Both operands are f32, so the product runs on the bf16 matrix unit as six plane products of the exact
+// three-way truncation split (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi -- smallest first; see gemm_tile_bf6 in
+// ftm_kernels.hip, whose arithmetic this kernel repeats term for term).
+//
+// What round 3's ablations of gemm_tile_bf6 showed (profiles/r03c_val_ablation.txt): that kernel is not waiting for the
+// matrix unit (without any MFMA it still takes 90 of its 108 us) but for its staging -- 36 KB of ds_write_b128 per
+// workgroup and K tile, two thirds of them the SAME d_out planes every one of the 1024 workgroups re-splits and re-stores,
+// behind two barriers per K tile.  This kernel removes the register->LDS path altogether:
+//   * D is split ONCE per launch into three bf16 planes in a workspace (split_planes_kernel, 0.75 MB) and its K tiles
+//     arrive in LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no VALU, no ds_write), double-buffered, the XOR swizzle
+//     of the image applied to the per-lane SOURCE address;
+//   * W never touches LDS: the four waves of a workgroup sit side by side along N (each 128 rows x 32 columns), so a table
+//     fragment is used by exactly one wave -- it is loaded in fragment layout straight into registers (lane = (column r, k
+//     octet q): two 16-byte loads, 128 contiguous bytes per table row and K tile), split there (44 VALU per 8 values) and
+//     multiplied against all eight row blocks of the tile;
+//   * 128 x 128 tiles: the D planes are staged half as often per column as with 128 x 64; one barrier per K tile.
+// Per wave and K tile of 32: 96 MFMAs (1536 matrix cycles), 24 ds_read_b128, ~120 VALU, 6 DMA pieces, 4 loads.
+#include <cstdlib>
+
+#include "common.h"
+#include "ftv_kernels.h"
+
+namespace {
+using u32x4 = __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned;
+using f32x4 = __attribute__((__vector_size__(4 * sizeof(float)))) float;
+using bf16x8 = __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16;
+
+constexpr int kBM = 128, kBN = 128, kKT = 32;
+constexpr int kPlane = kBM * kKT * 2;  // bytes of one plane of a K tile: 128 rows x 64 bytes
+constexpr int kBuf = 3 * kPlane;       // 24 KB; two buffers
+
+// [row][32 k] bf16 image, 64-byte rows, 16-byte chunk XOR-swizzled per block of four rows with {0, 3, 2, 1}: conflict-free
+// for the fragment read (16 rows x 4 chunks per ds_read_b128) under gfx950's lane groups (same image as bf6_img<32>)
+__device__ __forceinline__ int img(int row, int chunk) { return row * 64 + ((chunk ^ ((4 - (row >> 2)) & 3)) << 4); }
+
+// exact three-way truncation split of 8 consecutive k (two float4) into one 16-byte chunk of 8 bf16 per plane
+__device__ __forceinline__ void split8(const u32x4& v0, const u32x4& v1, u32x4& hi, u32x4& mid, u32x4& lo) {
+  unsigned h[8], m[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const unsigned xb = e < 4 ? v0[e] : v1[e - 4];
+    const float x = __uint_as_float(xb);
+    const unsigned hb = xb & 0xffff0000u;
+    const float r1 = x - __uint_as_float(hb);
+    const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(mb);
+    h[e] = hb; m[e] = mb; l[e] = __float_as_uint(r2);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {  // word t: k = 2 t (low half), 2 t + 1 (high half)
+    hi[t] = __builtin_amdgcn_perm(h[2 * t + 1], h[2 * t], 0x07060302u);
+    mid[t] = __builtin_amdgcn_perm(m[2 * t + 1], m[2 * t], 0x07060302u);
+    lo[t] = __builtin_amdgcn_perm(l[2 * t + 1], l[2 * t], 0x07060302u);
+  }
+}
+
+// d_out [rows][cols] f32 -> planes [3][rows][cols] bf16 (hi, mid, lo); one thread per 8 values
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, long long count8, long long plane_elems,
+                                                           unsigned short* __restrict__ planes) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count8) return;
+  const u32x4 v0 = *reinterpret_cast<const u32x4*>(src + i * 8), v1 = *reinterpret_cast<const u32x4*>(src + i * 8 + 4);
+  u32x4 hi, mid, lo;
+  split8(v0, v1, hi, mid, lo);
+  *reinterpret_cast<u32x4*>(planes + i * 8) = hi;
+  *reinterpret_cast<u32x4*>(planes + plane_elems + i * 8) = mid;
+  *reinterpret_cast<u32x4*>(planes + 2 * plane_elems + i * 8) = lo;
+}
+
+__device__ __forceinline__ void dma16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// ABL: timing-only ablations (tools/debug, wrong results unless 0): 1 no DMA after the first tile, 2 no table loads after the
+// first tile, 3 no MFMAs
+template <int ABL>
+__global__ __launch_bounds__(256) void ftv_values_kernel(const unsigned short* __restrict__ planes,  // [3][M][K] bf16
+                                                         const float* __restrict__ weight, unsigned weight_bytes, int stream_w,
+                                                         const uint8_t* __restrict__ bits, float* __restrict__ out, int M, int N, int K,
+                                                         int F) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * kBuf];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int n_base = blockIdx.x * kBN, m_base = blockIdx.y * kBM;
+  const int n_wave = n_base + 32 * wave;
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(weight), 0, weight_bytes, 0x00020000);
+  const int tiles = K / kKT;
+
+  // ---- D planes by LDS-DMA.  Piece = 1 KiB = 16 rows x 64 bytes of one plane; 24 pieces per K tile, six per wave.  Lane l
+  // lands at byte 16 l of the piece = (row 16 g + l / 4, physical chunk l % 4) and therefore fetches the logical chunk
+  // (l % 4) ^ swizzle(row).  Rows past M re-read row M - 1 (their accumulators are never stored).
+  const unsigned short* src_piece[6];
+  int dst_piece[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int piece = wave + 4 * i, plane = piece >> 3, g = piece & 7;
+    const int row = 16 * g + (lane >> 2);
+    const int chunk = (lane & 3) ^ ((4 - (row >> 2)) & 3);
+    const int m = m_base + row < M ? m_base + row : M - 1;
+    src_piece[i] = planes + ((size_t)plane * M + m) * K + chunk * 8;
+    dst_piece[i] = plane * kPlane + g * 1024;
+  }
+  auto issue_a = [&](int t, int buf) {
+    if constexpr (ABL == 1) {
+      if (t > 0) return;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dma16(src_piece[i] + (size_t)t * kKT, smem + buf * kBuf + dst_piece[i]);
+  };
+  // ---- table fragments straight into registers: column block j of this wave, lane (r, q) = 8 consecutive k of row
+  // min(n, F - 1); a table larger than the caches is read non-temporally
+  int w_off[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n_wave + 16 * j + r;
+    const int row = n < F - 1 ? n : F - 1;
+    w_off[j] = (row * K + 8 * q) * 4;
+  }
+  u32x4 rw[2][2];
+  auto load_w = [&](int t) {
+    if constexpr (ABL == 2) {
+      if (t > 0) return;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (stream_w) {
+        rw[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rsw, w_off[j] + t * (kKT * 4), 0, 2);
+        rw[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsw, w_off[j] + t * (kKT * 4) + 16, 0, 2);
+      } else {
+        rw[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rsw, w_off[j] + t * (kKT * 4), 0, 0);
+        rw[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsw, w_off[j] + t * (kKT * 4) + 16, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[8][2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int a_off[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a_off[i] = img(16 * i + r, q);
+
+  issue_a(0, 0);
+  load_w(0);
+  for (int t = 0; t < tiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile t have landed; its table registers are valid
+    u32x4 bw[3][2];                                     // [plane][column block]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) split8(rw[j][0], rw[j][1], bw[0][j], bw[1][j], bw[2][j]);
+    __syncthreads();  // every wave's pieces of tile t are in LDS; every wave is done reading the other buffer (tile t - 1)
+    if (t + 1 < tiles) {
+      issue_a(t + 1, (t + 1) & 1);
+      load_w(t + 1);
+    }
+    const unsigned char* __restrict__ buf = smem + (t & 1) * kBuf;
+    u32x4 a_cur[3], a_nxt[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) a_cur[p] = *reinterpret_cast<const u32x4*>(buf + p * kPlane + a_off[0]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (i + 1 < 8) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a_nxt[p] = *reinterpret_cast<const u32x4*>(buf + p * kPlane + a_off[i + 1]);
+      }
+      // smallest terms first (plane 0 = hi, 1 = mid, 2 = lo): lo hi, hi lo, mid mid, mid hi, hi mid, hi hi
+      constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+      if constexpr (ABL == 3) {
+#pragma unroll
+        for (int s = 0; s < 6; ++s)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j][0] += __uint_as_float(a_cur[pa[s]][0] ^ bw[pb[s]][j][0]);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 6; ++s)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_cur[pa[s]]), __builtin_bit_cast(bf16x8, bw[pb[s]][j]),
+                                                                acc[i][j], 0, 0, 0);
+      }
+      if (i + 1 < 8) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a_cur[p] = a_nxt[p];
+      }
+    }
+  }
+  // ---- epilogue: acc[i][j][e] = C[m_base + 16 i + 4 q + e][n_wave + 16 j + r], kept where the position is active
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    unsigned char bit[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m_base + 16 * i + 4 * q + e, n = n_wave + 16 * j + r;
+        const bool ok = m < M && n < N;
+        bit[j][e] = bits[ok ? (size_t)m * N + n : 0];
+      }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m_base + 16 * i + 4 * q + e, n = n_wave + 16 * j + r;
+        if (m < M && n < N) out[(size_t)m * N + n] = bit[j][e] ? acc[i][j][e] : 0.0f;
+      }
+  }
+}
+}  // namespace
+
+bool ftv_supported(int B, int F, int P, int L1) {
+  static const int on = [] { const char* e = getenv("NNUE_FTM_VAL_DMA"); return e ? atoi(e) : 1; }();  // developer knob
+  // big maps only: the 128 x 128 tiles must fill the chip, K runs in whole tiles of 32, every offset fits 31 bits
+  return on && B > 0 && L1 % kKT == 0 && P % 4 == 0 && (long long)((P + kBN - 1) / kBN) * ((B + kBM - 1) / kBM) >= 384 &&
+         (long long)F * L1 * 4 < (1ll << 31) && (long long)B * L1 * 2 < (1ll << 31);
+}
+
+int64_t ftv_scratch_bytes(int B, int L1) { return (int64_t)3 * B * L1 * 2; }
+
+int ftv_launch(const uint8_t* bits, const float* d_out, const float* weight, int B, int F, int P, int L1, float* d_conv_out, void* scratch,
+               hipStream_t st) {
+  unsigned short* planes = static_cast<unsigned short*>(scratch);
+  const long long count8 = (long long)B * L1 / 8;
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((count8 + 255) / 256)), dim3(256), 0, st, d_out, count8, (long long)B * L1, planes);
+  const dim3 grid((unsigned)((P + kBN - 1) / kBN), (unsigned)((B + kBM - 1) / kBM));
+  const unsigned wbytes = (unsigned)((size_t)F * L1 * 4);
+  const int stream_w = wbytes > (64u << 20);
+  static const int abl = [] { const char* e = getenv("NNUE_FTM_VAL_ABL"); return e ? atoi(e) : 0; }();  // timing-only ablations
+  if (abl == 1) hipLaunchKernelGGL(ftv_values_kernel<1>, grid, dim3(256), 0, st, planes, weight, wbytes, stream_w, bits, d_conv_out, B, P, L1, F);
+  else if (abl == 2) hipLaunchKernelGGL(ftv_values_kernel<2>, grid, dim3(256), 0, st, planes, weight, wbytes, stream_w, bits, d_conv_out, B, P, L1, F);
+  else if (abl == 3) hipLaunchKernelGGL(ftv_values_kernel<3>, grid, dim3(256), 0, st, planes, weight, wbytes, stream_w, bits, d_conv_out, B, P, L1, F);
+  else hipLaunchKernelGGL(ftv_values_kernel<0>, grid, dim3(256), 0, st, planes, weight, wbytes, stream_w, bits, d_conv_out, B, P, L1, F);
+  return NNUE_OK;
+}

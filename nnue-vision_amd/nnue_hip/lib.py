@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -69,6 +69,8 @@ SIGNATURES = {
     "nnue_ftm_forward_l1": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
     "nnue_ftm_backward_weight": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
     "nnue_ftm_backward_values": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p]),
+    "nnue_ftm_backward_values_scratch": (_c_i64, [_c_int, _c_int, _c_int, _c_int]),
+    "nnue_ftm_backward_values_ws": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_i64, _c_p]),
     "nnue_ftm_backward_cw_supported": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int]),
     "nnue_ftm_backward_sq_count": (_c_i64, [_c_int, _c_int, _c_int, _c_int]),
     "nnue_ftm_backward": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p,
@@ -613,7 +615,9 @@ class FeatureMatrix:
         return FeatureMatrix(torch.empty((batch, positions), dtype=torch.uint8, device=device),
                              torch.empty((batch,), dtype=torch.int32, device=device),
                              torch.empty((batch,), dtype=torch.float32, device=device),
-                             torch.empty((max(16, ftm_scratch_bytes(batch, num_rows, positions, l1)),), dtype=torch.uint8, device=device),
+                             torch.empty((max(16, ftm_scratch_bytes(batch, num_rows, positions, l1),
+                                              int(load().nnue_ftm_backward_values_scratch(batch, num_rows, positions, l1))),),
+                                         dtype=torch.uint8, device=device),
                              positions, num_rows)
 
 
@@ -731,8 +735,14 @@ def ftm_backward_values(d_out: torch.Tensor, weight: torch.Tensor, fm: FeatureMa
         dst = torch.empty((b, fm.positions), dtype=torch.float32, device=d_out.device)
     elif dst.numel() != b * fm.positions:
         raise ValueError("ftm_backward_values: dst has the wrong size")
-    _call("nnue_ftm_backward_values", fm.bits.data_ptr(), d_out.data_ptr(), weight.data_ptr(), b, fm.num_rows, fm.positions,
-          l1, dst.data_ptr(), _stream(d_out))
+    # big maps: d_out is split once into bf16 planes in a workspace (csrc/ftv_kernels.hip) -- the forward's split-K scratch,
+    # free at this point of a step, serves when it is large enough
+    need = int(load().nnue_ftm_backward_values_scratch(b, fm.num_rows, fm.positions, l1))
+    ws = fm.scratch if (need and fm.scratch is not None and fm.scratch.numel() >= need) else None
+    if need and ws is None:
+        ws = fm.scratch = torch.empty((need,), dtype=torch.uint8, device=d_out.device)
+    _call("nnue_ftm_backward_values_ws", fm.bits.data_ptr(), d_out.data_ptr(), weight.data_ptr(), b, fm.num_rows, fm.positions,
+          l1, dst.data_ptr(), _ptr(ws) if need else None, need, _stream(d_out))
     return dst
 
 

@@ -40,6 +40,7 @@ SHAPES = [  # B, fps, Gh, Gw, F, L1: the CIFAR map (clamp sink), exact-fit map, 
     (512, 8, 11, 11, 800, 1024), (64, 8, 11, 11, 800, 256), (37, 4, 8, 8, 256, 64), (5, 4, 3, 3, 100, 36),
     (16, 64, 8, 8, 4096, 128), (3, 2, 2, 1, 3, 4), (130, 8, 10, 10, 800, 200), (33, 12, 5, 5, 150, 72), (1, 4, 1, 1, 4, 8),
     (24, 64, 32, 32, 65536, 256), (140, 64, 24, 24, 30000, 136),  # big maps: bf16-split tiles incl. the six-product value gradient
+    (130, 64, 24, 24, 30000, 128), (128, 64, 32, 32, 65536, 64),  # ... and the LDS-DMA value gradient (ftv_kernels.hip): row tail, clamp, two row tiles
 ]
 
 
