@@ -9,6 +9,8 @@
 // on plain-VALU "simple" kernels otherwise.  The two narrow layers (L2 -> L3 -> C) are a per-sample
 // tail kernel working out of LDS.  Split-K partials are summed in fixed order: reproducible.
 #include <type_traits>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -1250,7 +1252,10 @@ int train_step_impl(const float* x, int pairwise, const float* w1, const float* 
       } else if (wgrad_rides) {
         const long long waves = (long long)m_tiles * (L1 / 32);
         const int x_blocks = (int)((waves + 3) / 4);
-        hipLaunchKernelGGL(l1_backward_x_small_wgrad, dim3((unsigned)(x_blocks + wgrad_blocks)), dim3(256), 0, s, x, pairwise, w1,
+        // timing-only ablation (tools/debug, WRONG small gradients): the d_x blocks alone -- what the launch would cost if the small
+        // gradients rode elsewhere
+        static const int skip_small = [] { const char* e = getenv("NNUE_CLS_ABL_SKIP_SMALL"); return e ? atoi(e) : 0; }();
+        hipLaunchKernelGGL(l1_backward_x_small_wgrad, dim3((unsigned)(x_blocks + (skip_small ? 0 : wgrad_blocks))), dim3(256), 0, s, x, pairwise, w1,
                            (const float*)d_z1, B, L1, L2, d_x, x_blocks, sw);
       } else if (p.bwx_mfma) {
         const long long waves = (long long)m_tiles * (L1 / 32);

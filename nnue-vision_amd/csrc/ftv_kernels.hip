@@ -16,9 +16,13 @@
 //     fragment is used by exactly one wave -- it is loaded in fragment layout straight into registers (lane = (column r, k
 //     octet q): two 16-byte loads, 128 contiguous bytes per table row and K tile), split there (44 VALU per 8 values) and
 //     multiplied against all eight row blocks of the tile;
-//   * 128 x 128 tiles: the D planes are staged half as often per column as with 128 x 64; one barrier per K tile.
+//   * 128 x 128 tiles: the D planes are staged half as often per column as with 128 x 64; one barrier per K tile;
+//   * three K tiles in flight per wave (the first version, one tile ahead behind a vmcnt(0), was latency-bound on the table
+//     stream: 32 KB in flight per CU; without any MFMA it still took 76 of its 101 us): the table loads are inline assembly so
+//     that the compiler does not drain the queue, and a counted s_waitcnt hands their registers back.
 // Per wave and K tile of 32: 96 MFMAs (1536 matrix cycles), 24 ds_read_b128, ~120 VALU, 6 DMA pieces, 4 loads.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "ftv_kernels.h"
@@ -30,7 +34,7 @@ using bf16x8 = __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16;
 
 constexpr int kBM = 128, kBN = 128, kKT = 32;
 constexpr int kPlane = kBM * kKT * 2;  // bytes of one plane of a K tile: 128 rows x 64 bytes
-constexpr int kBuf = 3 * kPlane;       // 24 KB; two buffers
+constexpr int kBuf = 3 * kPlane;       // 24 KB per K tile; kDepth of them
 
 // [row][32 k] bf16 image, 64-byte rows, 16-byte chunk XOR-swizzled per block of four rows with {0, 3, 2, 1}: conflict-free
 // for the fragment read (16 rows x 4 chunks per ds_read_b128) under gfx950's lane groups (same image as bf6_img<32>)
@@ -74,20 +78,35 @@ __device__ __forceinline__ void dma16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-// ABL: timing-only ablations (tools/debug, wrong results unless 0): 1 no DMA after the first tile, 2 no table loads after the
-// first tile, 3 no MFMAs
-template <int ABL>
-__global__ __launch_bounds__(256) void ftv_values_kernel(const unsigned short* __restrict__ planes,  // [3][M][K] bf16
-                                                         const float* __restrict__ weight, unsigned weight_bytes, int stream_w,
-                                                         const uint8_t* __restrict__ bits, float* __restrict__ out, int M, int N, int K,
-                                                         int F) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * kBuf];
+// One 16-byte table load whose completion the COMPILER does not track (inline assembly): with LDS-DMA in flight hipcc would
+// otherwise wait vmcnt(0) at the first use of any ordinary load result and so drain the whole prefetch queue each K tile.
+// The registers are handed back by wait_tiles(), which carries them as in/out operands of the counted s_waitcnt.
+template <bool NT>
+__device__ __forceinline__ void load16(u32x4& dst, const float* base, unsigned off) {
+  if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(off), "s"(base) : "memory");
+  else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory");
+}
+template <bool NT>
+__device__ __forceinline__ void load16_hi(u32x4& dst, const float* base, unsigned off) {
+  if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, %2 offset:16 nt" : "=v"(dst) : "v"(off), "s"(base) : "memory");
+  else asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(dst) : "v"(off), "s"(base) : "memory");
+}
+
+constexpr int kDepth = 3;            // K tiles in flight: tile t computes while t + 1 and t + 2 travel
+constexpr int kOpsPerTile = 6 + 4;   // per wave: six DMA pieces, then four table loads (issue order = vmcnt order)
+
+// ABL: timing-only ablations (tools/debug, wrong results unless 0): 1 no DMA after the prologue, 2 no table loads after the
+// prologue.  (A "no MFMA" variant spilled 109 registers to scratch beside the asm loads and faulted: not kept.)
+template <int ABL, bool NT>
+__global__ __launch_bounds__(256, 2) void ftv_values_kernel(const unsigned short* __restrict__ planes,  // [3][M][K] bf16
+                                                         const float* __restrict__ weight, const uint8_t* __restrict__ bits,
+                                                         float* __restrict__ out, int M, int N, int K, int F) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[kDepth * kBuf];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
   const int n_base = blockIdx.x * kBN, m_base = blockIdx.y * kBM;
   const int n_wave = n_base + 32 * wave;
-  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(weight), 0, weight_bytes, 0x00020000);
   const int tiles = K / kKT;
 
   // ---- D planes by LDS-DMA.  Piece = 1 KiB = 16 rows x 64 bytes of one plane; 24 pieces per K tile, six per wave.  Lane l
@@ -104,35 +123,27 @@ __global__ __launch_bounds__(256) void ftv_values_kernel(const unsigned short* _
     src_piece[i] = planes + ((size_t)plane * M + m) * K + chunk * 8;
     dst_piece[i] = plane * kPlane + g * 1024;
   }
-  auto issue_a = [&](int t, int buf) {
-    if constexpr (ABL == 1) {
-      if (t > 0) return;
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) dma16(src_piece[i] + (size_t)t * kKT, smem + buf * kBuf + dst_piece[i]);
-  };
   // ---- table fragments straight into registers: column block j of this wave, lane (r, q) = 8 consecutive k of row
-  // min(n, F - 1); a table larger than the caches is read non-temporally
-  int w_off[2];
+  // min(n, F - 1): two 16-byte loads, 128 contiguous bytes per table row and K tile
+  unsigned w_off[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = n_wave + 16 * j + r;
     const int row = n < F - 1 ? n : F - 1;
-    w_off[j] = (row * K + 8 * q) * 4;
+    w_off[j] = (unsigned)(row * K + 8 * q) * 4u;
   }
-  u32x4 rw[2][2];
-  auto load_w = [&](int t) {
-    if constexpr (ABL == 2) {
-      if (t > 0) return;
-    }
+  u32x4 rw[kDepth][2][2];
+  auto issue = [&](int t, auto slot_tag) {  // tile t into slot t % kDepth: DMA pieces first, table loads after them
+    constexpr int S = decltype(slot_tag)::value;
+    if (!(ABL == 1 && t >= kDepth)) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (stream_w) {
-        rw[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rsw, w_off[j] + t * (kKT * 4), 0, 2);
-        rw[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsw, w_off[j] + t * (kKT * 4) + 16, 0, 2);
-      } else {
-        rw[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rsw, w_off[j] + t * (kKT * 4), 0, 0);
-        rw[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsw, w_off[j] + t * (kKT * 4) + 16, 0, 0);
+      for (int i = 0; i < 6; ++i) dma16(src_piece[i] + (size_t)t * kKT, smem + S * kBuf + dst_piece[i]);
+    }
+    if (!(ABL == 2 && t >= kDepth)) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        load16<NT>(rw[S][j][0], weight, w_off[j] + (unsigned)t * (kKT * 4));
+        load16_hi<NT>(rw[S][j][1], weight, w_off[j] + (unsigned)t * (kKT * 4));
       }
     }
   };
@@ -146,19 +157,25 @@ __global__ __launch_bounds__(256) void ftv_values_kernel(const unsigned short* _
 #pragma unroll
   for (int i = 0; i < 8; ++i) a_off[i] = img(16 * i + r, q);
 
-  issue_a(0, 0);
-  load_w(0);
-  for (int t = 0; t < tiles; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile t have landed; its table registers are valid
-    u32x4 bw[3][2];                                     // [plane][column block]
-#pragma unroll
-    for (int j = 0; j < 2; ++j) split8(rw[j][0], rw[j][1], bw[0][j], bw[1][j], bw[2][j]);
-    __syncthreads();  // every wave's pieces of tile t are in LDS; every wave is done reading the other buffer (tile t - 1)
-    if (t + 1 < tiles) {
-      issue_a(t + 1, (t + 1) & 1);
-      load_w(t + 1);
-    }
-    const unsigned char* __restrict__ buf = smem + (t & 1) * kBuf;
+  // One K tile.
+  auto step = [&](int t, auto slot_tag) {
+    constexpr int S = decltype(slot_tag)::value;
+    u32x4 &w00 = rw[S][0][0], &w01 = rw[S][0][1], &w10 = rw[S][1][0], &w11 = rw[S][1][1];
+    // On entry tiles t and t + 1 are in flight (t + 2 is issued below, after the barrier has freed its slot): everything of
+    // tile t must have landed, tile t + 1's ten operations may stay out.  The registers come back through the operands -- an
+    // asm load's destination counts as written at the statement, so without this hand-back the compiler may reuse it before
+    // the data lands (a too-large count here showed up as a memory fault: a late load landed in a register holding an address).
+    if (ABL == 1 || ABL == 2 || t + 1 >= tiles) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w00), "+v"(w01), "+v"(w10), "+v"(w11)::"memory");
+    else asm volatile("s_waitcnt vmcnt(10)" : "+v"(w00), "+v"(w01), "+v"(w10), "+v"(w11)::"memory");
+    static_assert(kOpsPerTile == 10 && kDepth == 3, "the counted wait above is one tile's operations");
+    u32x4 bw[3][2];  // [plane][column block]
+    split8(w00, w01, bw[0][0], bw[1][0], bw[2][0]);
+    split8(w10, w11, bw[0][1], bw[1][1], bw[2][1]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave's pieces of tile t are in LDS; every wave is done with tile t - 1 (slot (t - 1) % 3)
+    asm volatile("" ::: "memory");
+    if (t + kDepth - 1 < tiles) issue(t + kDepth - 1, std::integral_constant<int, (S + kDepth - 1) % kDepth>{});
+    const unsigned char* __restrict__ buf = smem + S * kBuf;
     u32x4 a_cur[3], a_nxt[3];
 #pragma unroll
     for (int p = 0; p < 3; ++p) a_cur[p] = *reinterpret_cast<const u32x4*>(buf + p * kPlane + a_off[0]);
@@ -170,25 +187,31 @@ __global__ __launch_bounds__(256) void ftv_values_kernel(const unsigned short* _
       }
       // smallest terms first (plane 0 = hi, 1 = mid, 2 = lo): lo hi, hi lo, mid mid, mid hi, hi mid, hi hi
       constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
-      if constexpr (ABL == 3) {
 #pragma unroll
-        for (int s = 0; s < 6; ++s)
+      for (int s = 0; s < 6; ++s)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j][0] += __uint_as_float(a_cur[pa[s]][0] ^ bw[pb[s]][j][0]);
-      } else {
-#pragma unroll
-        for (int s = 0; s < 6; ++s)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_cur[pa[s]]), __builtin_bit_cast(bf16x8, bw[pb[s]][j]),
-                                                                acc[i][j], 0, 0, 0);
-      }
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_cur[pa[s]]), __builtin_bit_cast(bf16x8, bw[pb[s]][j]),
+                                                              acc[i][j], 0, 0, 0);
       if (i + 1 < 8) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) a_cur[p] = a_nxt[p];
       }
     }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  issue(0, S0{});
+  if (tiles > 1) issue(1, S1{});
+  int t = 0;
+  for (; t + 3 <= tiles; t += 3) {
+    step(t, S0{});
+    step(t + 1, S1{});
+    step(t + 2, S2{});
   }
+  if (t < tiles) step(t++, S0{});
+  if (t < tiles) step(t++, S1{});
   // ---- epilogue: acc[i][j][e] = C[m_base + 16 i + 4 q + e][n_wave + 16 j + r], kept where the position is active
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -227,12 +250,16 @@ int ftv_launch(const uint8_t* bits, const float* d_out, const float* weight, int
   const long long count8 = (long long)B * L1 / 8;
   hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((count8 + 255) / 256)), dim3(256), 0, st, d_out, count8, (long long)B * L1, planes);
   const dim3 grid((unsigned)((P + kBN - 1) / kBN), (unsigned)((B + kBM - 1) / kBM));
-  const unsigned wbytes = (unsigned)((size_t)F * L1 * 4);
-  const int stream_w = wbytes > (64u << 20);
+  const bool nt = (size_t)F * L1 * 4 > (64u << 20);  // a table larger than the caches is streamed once: non-temporal loads
   static const int abl = [] { const char* e = getenv("NNUE_FTM_VAL_ABL"); return e ? atoi(e) : 0; }();  // timing-only ablations
-  if (abl == 1) hipLaunchKernelGGL(ftv_values_kernel<1>, grid, dim3(256), 0, st, planes, weight, wbytes, stream_w, bits, d_conv_out, B, P, L1, F);
-  else if (abl == 2) hipLaunchKernelGGL(ftv_values_kernel<2>, grid, dim3(256), 0, st, planes, weight, wbytes, stream_w, bits, d_conv_out, B, P, L1, F);
-  else if (abl == 3) hipLaunchKernelGGL(ftv_values_kernel<3>, grid, dim3(256), 0, st, planes, weight, wbytes, stream_w, bits, d_conv_out, B, P, L1, F);
-  else hipLaunchKernelGGL(ftv_values_kernel<0>, grid, dim3(256), 0, st, planes, weight, wbytes, stream_w, bits, d_conv_out, B, P, L1, F);
+#define NNUE_FTV(A)                                                                                                                         \
+  do {                                                                                                                                      \
+    if (nt) hipLaunchKernelGGL((ftv_values_kernel<A, true>), grid, dim3(256), 0, st, planes, weight, bits, d_conv_out, B, P, L1, F);         \
+    else hipLaunchKernelGGL((ftv_values_kernel<A, false>), grid, dim3(256), 0, st, planes, weight, bits, d_conv_out, B, P, L1, F);           \
+  } while (0)
+  if (abl == 1) NNUE_FTV(1);
+  else if (abl == 2) NNUE_FTV(2);
+  else NNUE_FTV(0);
+#undef NNUE_FTV
   return NNUE_OK;
 }

@@ -18,4 +18,4 @@ run dma
 run old NNUE_FTM_VAL_DMA=0
 run abl1 NNUE_FTM_VAL_ABL=1
 run abl2 NNUE_FTM_VAL_ABL=2
-run abl3 NNUE_FTM_VAL_ABL=3
+
