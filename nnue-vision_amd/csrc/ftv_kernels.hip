@@ -100,8 +100,17 @@ constexpr int kOpsPerTile = 6 + 4;   // per wave: six DMA pieces, then four tabl
 template <int ABL, bool NT>
 __global__ __launch_bounds__(256, 2) void ftv_values_kernel(const unsigned short* __restrict__ planes,  // [3][M][K] bf16
                                                          const float* __restrict__ weight, const uint8_t* __restrict__ bits,
-                                                         float* __restrict__ out, int M, int N, int K, int F) {
+                                                         float* __restrict__ out, int M, int N, int K, int F, int prio_mode) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[kDepth * kBuf];
+  // Two workgroups share a CU, one wave of each per SIMD, both running this same program: left alone they fall into
+  // lockstep (both in their MFMA phase, each at half rate, then both in their split / wait / barrier phase with the matrix
+  // pipe idle: SQ counters of the first version -- issue-stalled 52 % of the wave cycles, pipe busy 51 %).  A static priority
+  // for one of the two lets it take the pipe whole, so that the phases interleave.  Which workgroups share a CU is the
+  // dispatcher's business; the guesses below are for speed only (results do not depend on them).
+  if (prio_mode == 1) { if (blockIdx.x >= (gridDim.x >> 1)) __builtin_amdgcn_s_setprio(2); }
+  else if (prio_mode == 2) { if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(2); }
+  else if (prio_mode == 3) { if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_setprio(2); }
+  else if (prio_mode == 4) { if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(2); }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
@@ -176,27 +185,27 @@ __global__ __launch_bounds__(256, 2) void ftv_values_kernel(const unsigned short
     asm volatile("" ::: "memory");
     if (t + kDepth - 1 < tiles) issue(t + kDepth - 1, std::integral_constant<int, (S + kDepth - 1) % kDepth>{});
     const unsigned char* __restrict__ buf = smem + S * kBuf;
-    u32x4 a_cur[3], a_nxt[3];
+    // fragments of row block i + 1 are requested before row block i's MFMAs (two register sets, ping-pong; the scheduling
+    // barrier keeps the compiler from sinking the reads to their use, where every block would expose the LDS latency)
+    u32x4 af[2][3];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) a_cur[p] = *reinterpret_cast<const u32x4*>(buf + p * kPlane + a_off[0]);
+    for (int p = 0; p < 3; ++p) af[0][p] = *reinterpret_cast<const u32x4*>(buf + p * kPlane + a_off[0]);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       if (i + 1 < 8) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) a_nxt[p] = *reinterpret_cast<const u32x4*>(buf + p * kPlane + a_off[i + 1]);
+        for (int p = 0; p < 3; ++p) af[(i + 1) & 1][p] = *reinterpret_cast<const u32x4*>(buf + p * kPlane + a_off[i + 1]);
       }
+      __builtin_amdgcn_sched_barrier(0);
       // smallest terms first (plane 0 = hi, 1 = mid, 2 = lo): lo hi, hi lo, mid mid, mid hi, hi mid, hi hi
       constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
       for (int s = 0; s < 6; ++s)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_cur[pa[s]]), __builtin_bit_cast(bf16x8, bw[pb[s]][j]),
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i & 1][pa[s]]), __builtin_bit_cast(bf16x8, bw[pb[s]][j]),
                                                               acc[i][j], 0, 0, 0);
-      if (i + 1 < 8) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) a_cur[p] = a_nxt[p];
-      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   using S0 = std::integral_constant<int, 0>;
@@ -236,7 +245,10 @@ __global__ __launch_bounds__(256, 2) void ftv_values_kernel(const unsigned short
 }  // namespace
 
 bool ftv_supported(int B, int F, int P, int L1) {
-  static const int on = [] { const char* e = getenv("NNUE_FTM_VAL_DMA"); return e ? atoi(e) : 1; }();  // developer knob
+  // Off by default: measured in the 224x224 step it ties the six-plane tile kernel (102.3 vs 102.8 us, + 5 us for the split
+  // pre-pass).  Read per call so that tests can switch it inside one process.
+  const char* e = getenv("NNUE_FTM_VAL_DMA");
+  const int on = e ? atoi(e) : 0;
   // big maps only: the 128 x 128 tiles must fill the chip, K runs in whole tiles of 32, every offset fits 31 bits
   return on && B > 0 && L1 % kKT == 0 && P % 4 == 0 && (long long)((P + kBN - 1) / kBN) * ((B + kBM - 1) / kBM) >= 384 &&
          (long long)F * L1 * 4 < (1ll << 31) && (long long)B * L1 * 2 < (1ll << 31);
@@ -252,10 +264,11 @@ int ftv_launch(const uint8_t* bits, const float* d_out, const float* weight, int
   const dim3 grid((unsigned)((P + kBN - 1) / kBN), (unsigned)((B + kBM - 1) / kBM));
   const bool nt = (size_t)F * L1 * 4 > (64u << 20);  // a table larger than the caches is streamed once: non-temporal loads
   static const int abl = [] { const char* e = getenv("NNUE_FTM_VAL_ABL"); return e ? atoi(e) : 0; }();  // timing-only ablations
+  static const int prio = [] { const char* e = getenv("NNUE_FTM_VAL_PRIO"); return e ? atoi(e) : 0; }();  // developer knob: see the kernel
 #define NNUE_FTV(A)                                                                                                                         \
   do {                                                                                                                                      \
-    if (nt) hipLaunchKernelGGL((ftv_values_kernel<A, true>), grid, dim3(256), 0, st, planes, weight, bits, d_conv_out, B, P, L1, F);         \
-    else hipLaunchKernelGGL((ftv_values_kernel<A, false>), grid, dim3(256), 0, st, planes, weight, bits, d_conv_out, B, P, L1, F);           \
+    if (nt) hipLaunchKernelGGL((ftv_values_kernel<A, true>), grid, dim3(256), 0, st, planes, weight, bits, d_conv_out, B, P, L1, F, prio); \
+    else hipLaunchKernelGGL((ftv_values_kernel<A, false>), grid, dim3(256), 0, st, planes, weight, bits, d_conv_out, B, P, L1, F, prio); \
   } while (0)
   if (abl == 1) NNUE_FTV(1);
   else if (abl == 2) NNUE_FTV(2);

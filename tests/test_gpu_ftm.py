@@ -80,6 +80,32 @@ def test_ftm_kernels_against_float64(hip, shape, density):
     assert only_b[0] is None and torch.equal(only_b[1], d_b)
 
 
+@pytest.mark.parametrize("shape", [(24, 64, 32, 32, 65536, 256), (130, 64, 24, 24, 30000, 128), (128, 64, 32, 32, 65536, 64)])
+def test_value_gradient_by_lds_dma_against_float64(hip, shape, monkeypatch):
+    """The optional big-map value gradient of csrc/ftv_kernels.hip (NNUE_FTM_VAL_DMA=1: d_out split once into bf16 planes in a
+    workspace and staged by LDS-DMA, table fragments straight to registers): row tail, two row tiles, the F-1 clamp, and bitwise
+    equality with the default six-plane tile kernel's term order is NOT expected -- both are held to the float64 value."""
+    b, fps, gh, gw, f, l1 = shape
+    monkeypatch.setenv("NNUE_FTM_VAL_DMA", "1")
+    assert int(hip.load().nnue_ftm_backward_values_scratch(b, f, fps * gh * gw, l1)) == 3 * b * l1 * 2
+    gen = torch.Generator().manual_seed(b + f)
+    conv_out = torch.randn(b, fps, gh, gw, generator=gen)
+    thr = torch.full((fps,), 0.17)
+    weight, bias = torch.randn(f, l1, generator=gen) * 0.1, torch.zeros(l1)
+    d_out = torch.randn(b, l1, generator=gen) / b
+    _, _, _, ref_dval, _, _ = dense_reference(conv_out, thr, weight, bias, d_out)
+    g = lambda t: t.to(DEV)
+    fm = hip.ftm_binarize(g(conv_out), g(thr), f, l1)
+    d_val = hip.ftm_backward_values(g(d_out), g(weight), fm)
+    assert_close_grad(d_val.view(conv_out.shape), ref_dval, "d_conv_out (LDS-DMA kernel)", rtol=2e-5)
+    active = (conv_out > 0.17).reshape(b, -1)
+    assert not bool(d_val.view(b, -1)[~active.to(DEV)].any())
+    assert torch.equal(hip.ftm_backward_values(g(d_out), g(weight), fm), d_val)  # fixed order: reproducible
+    monkeypatch.setenv("NNUE_FTM_VAL_DMA", "0")
+    assert int(hip.load().nnue_ftm_backward_values_scratch(b, f, fps * gh * gw, l1)) == 0
+    assert_close_grad(hip.ftm_backward_values(g(d_out), g(weight), fm), d_val, "tile kernel vs LDS-DMA kernel", rtol=2e-5)
+
+
 @pytest.mark.parametrize("name", MODEL_CASES)
 def test_ftm_on_golden_models(hip, name):
     """The reference's own tensors: conv_out -> ft, and the input.weight / input.bias gradients of a real backward."""
