@@ -998,7 +998,10 @@ __device__ __forceinline__ void split8(const u32x4& v0, const u32x4& v1, u32x4& 
 
 // ABL: timing-only ablations for tools/debug (results are WRONG unless 0): 1 no split of A (raw words stored), 2 no split at
 // all, 3 no MFMAs (fragments still read), 4 no staging (no split, no LDS stores), 5 no global loads
-template <int BM, int BN, class Epi, int KT = kBf6K, int ABL = 0>
+// APL: operand A arrives already split -- ma.p = K-tile-major planes [K / 32][3][M][32] bf16 (hi, mid, lo; ftv_split_planes), KT = 32: three 16-byte loads per 8-k
+// run and no split VALU for it (the d_out planes of nnue_ftm_backward_values_ws).  This kernel is issue-bound (MFMA and VALU issue
+// add up on a SIMD, tools/micro/mfma_bf16_tile.hip), and two thirds of its split work is the same d_out rows in every workgroup.
+template <int BM, int BN, class Epi, int KT = kBf6K, int ABL = 0, bool APL = false>
 __device__ __forceinline__ void gemm_tile_bf6(unsigned char* __restrict__ smem, const Mat& ma, const Mat& mb, const Epi& epi, int M, int N,
                                               int k_lo, int k_hi, int tiles_n, int tile, int ks) {
   static_assert((BM == 32 || BM == 64 || BM == 128) && (BN == 64 || BN == 128), "tile shapes");
@@ -1018,7 +1021,7 @@ __device__ __forceinline__ void gemm_tile_bf6(unsigned char* __restrict__ smem, 
   constexpr int GA = BM * RUNS / 256, GB = BN * RUNS / 256;  // 8-k runs per thread
   static_assert(GA >= 1 && GB >= 1, "every thread stages at least one run of each operand");
   const bool stream_b = mb.bytes > (64u << 20);        // uniform: a table larger than the caches is read non-temporally
-  u32x4 ra[GA][2], rb[GB][2];
+  u32x4 ra[GA][APL ? 3 : 2], rb[GB][2];
   auto fetch = [&](int k0) {
     if constexpr (ABL == 5) {
       if (k0 != k_lo) return;
@@ -1026,8 +1029,15 @@ __device__ __forceinline__ void gemm_tile_bf6(unsigned char* __restrict__ smem, 
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
       const int g = tid + 256 * i, row = g / RUNS, k = k0 + (g % RUNS) * 8;
-      ra[i][0] = mat_load<false>(rsa, ma, m_base + row, k);
-      ra[i][1] = mat_load<false>(rsa, ma, m_base + row, k + 4);
+      if constexpr (APL) {  // rows past M re-read row M - 1: their accumulators are never stored
+        const int rr = m_base + row < M ? m_base + row : M - 1;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          ra[i][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsa, ((((k >> 5) * 3 + pl) * M + rr) * 32 + (k & 31)) * 2, 0, 0);
+      } else {
+        ra[i][0] = mat_load<false>(rsa, ma, m_base + row, k);
+        ra[i][1] = mat_load<false>(rsa, ma, m_base + row, k + 4);
+      }
     }
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
@@ -1049,7 +1059,8 @@ __device__ __forceinline__ void gemm_tile_bf6(unsigned char* __restrict__ smem, 
     for (int i = 0; i < GA; ++i) {
       const int g = tid + 256 * i, row = g / RUNS, c = g % RUNS;
       u32x4 hi, mid, lo;
-      if constexpr (ABL == 1 || ABL == 2) { hi = ra[i][0]; mid = ra[i][1]; lo = ra[i][0] ^ ra[i][1]; }
+      if constexpr (APL) { hi = ra[i][0]; mid = ra[i][1]; lo = ra[i][2]; }
+      else if constexpr (ABL == 1 || ABL == 2) { hi = ra[i][0]; mid = ra[i][1]; lo = ra[i][0] ^ ra[i][1]; }
       else split8(ra[i][0], ra[i][1], hi, mid, lo);
       *reinterpret_cast<u32x4*>(As + bf6_img<KT>(row, c)) = hi;
       *reinterpret_cast<u32x4*>(As + PA + bf6_img<KT>(row, c)) = mid;
@@ -1113,10 +1124,10 @@ __device__ __forceinline__ void gemm_tile_bf6(unsigned char* __restrict__ smem, 
   store_tile<BM, BN, Epi>(reinterpret_cast<float*>(smem), epi, acc, M, N, m_base, n_base, m0, n0, tile, ks);
 }
 
-template <int BM, int BN, class Epi, int KT, int ABL = 0>
+template <int BM, int BN, class Epi, int KT, int ABL = 0, bool APL = false>
 __global__ __launch_bounds__(256) void ftm_gemm_bf6_kernel(Mat ma, Mat mb, Epi epi, int M, int N, int K, int tiles_n) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[gemm_bf6_lds_bytes<BM, BN, KT>()];
-  gemm_tile_bf6<BM, BN, Epi, KT, ABL>(smem, ma, mb, epi, M, N, 0, K, tiles_n, blockIdx.x, 0);
+  gemm_tile_bf6<BM, BN, Epi, KT, ABL, APL>(smem, ma, mb, epi, M, N, 0, K, tiles_n, blockIdx.x, 0);
 }
 
 template <int BM, int BN, bool AKC, class Epi>
@@ -1831,9 +1842,21 @@ extern "C" int nnue_ftm_backward_values(const uint8_t* bits, const float* d_out,
 // The same value gradient with a workspace: big maps take ftv_kernels.hip (d_out split once into bf16 planes in the
 // workspace and staged by LDS-DMA, table fragments straight into registers); every other shape, or a call without enough
 // workspace for it, runs nnue_ftm_backward_values unchanged.
+namespace {
+// the six-plane tile kernel fed with d_out planes from the workspace (K in whole tiles of 32; offsets fit 31 bits)
+bool values_planes(int B, int P, int L1) {
+  // Off by default: measured in the 224x224 step this is SLOWER than splitting d_out in every workgroup (125.6 vs 98.8 us): three
+  // 16-byte plane loads per run instead of two float loads put 1.36x the bytes through the CUs' load path, which is what the tile
+  // kernel waits for -- not its split VALU.  Read per call (tests switch it).
+  const char* e = getenv("NNUE_FTM_VAL_PLANES");
+  return (e ? atoi(e) : 0) && values_bf6(B, P, L1) && L1 % 32 == 0 && (long long)3 * B * L1 * 2 < (1ll << 31);
+}
+}  // namespace
+
 extern "C" int64_t nnue_ftm_backward_values_scratch(int B, int F, int P, int L1) {
   if (!nnue_ftm_supported(F, P, L1) || !shape_ok(B, F, P, L1)) return 0;
-  return (values_bf6(B, P, L1) && ftv_supported(B, F, P, L1)) ? ftv_scratch_bytes(B, L1) : 0;
+  if (values_bf6(B, P, L1) && ftv_supported(B, F, P, L1)) return ftv_scratch_bytes(B, L1);
+  return values_planes(B, P, L1) ? ftv_scratch_bytes(B, L1) : 0;
 }
 
 extern "C" int nnue_ftm_backward_values_ws(const uint8_t* bits, const float* d_out, const float* weight, int B, int F, int P, int L1,
@@ -1845,7 +1868,18 @@ extern "C" int nnue_ftm_backward_values_ws(const uint8_t* bits, const float* d_o
                (long long)need, (long long)scratch_bytes);
   NNUE_REQUIRE(nnue_aligned16(d_out) && nnue_aligned16(weight) && nnue_aligned16(scratch), NNUE_E_ARG,
                "nnue_ftm_backward_values_ws: pointers must be 16-byte aligned");
-  ftv_launch(bits, d_out, weight, B, F, P, L1, d_conv_out, scratch, static_cast<hipStream_t>(stream));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (values_bf6(B, P, L1) && ftv_supported(B, F, P, L1)) {
+    ftv_launch(bits, d_out, weight, B, F, P, L1, d_conv_out, scratch, st);
+    return nnue_launch_status("nnue_ftm_backward_values_ws");
+  }
+  // d_out split once per launch; the 128 x 64 x 32 six-plane tiles take its planes as they are (no split VALU for operand A)
+  ftv_split_planes(d_out, B, L1, scratch, st);
+  const Shape s = plan(B, P, L1, true, false);
+  const Mat ma{scratch, (unsigned)((size_t)3 * B * L1 * 2), L1, kIntMax, L1}, mb{weight, (unsigned)((size_t)F * L1 * 4), L1, F - 1, kIntMax};
+  const ValEpi epi{bits, d_conv_out, P};
+  hipLaunchKernelGGL((ftm_gemm_bf6_kernel<128, 64, ValEpi, 32, 0, true>), dim3((unsigned)(s.tiles_m * s.tiles_n)), dim3(256), 0, st, ma, mb, epi, B, P,
+                     L1, s.tiles_n);
   return nnue_launch_status("nnue_ftm_backward_values_ws");
 }
 

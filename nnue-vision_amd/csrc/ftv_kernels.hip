@@ -32,7 +32,7 @@ using u32x4 = __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned;
 using f32x4 = __attribute__((__vector_size__(4 * sizeof(float)))) float;
 using bf16x8 = __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16;
 
-constexpr int kBM = 128, kBN = 128, kKT = 32;
+constexpr int kBM = 128, kKT = 32;  // tile rows, K tile; the tile is 64 * NB columns wide (NB = 16-column blocks per wave: 2 or 4)
 constexpr int kPlane = kBM * kKT * 2;  // bytes of one plane of a K tile: 128 rows x 64 bytes
 constexpr int kBuf = 3 * kPlane;       // 24 KB per K tile; kDepth of them
 
@@ -61,17 +61,22 @@ __device__ __forceinline__ void split8(const u32x4& v0, const u32x4& v1, u32x4& 
   }
 }
 
-// d_out [rows][cols] f32 -> planes [3][rows][cols] bf16 (hi, mid, lo); one thread per 8 values
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, long long count8, long long plane_elems,
-                                                           unsigned short* __restrict__ planes) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= count8) return;
+// d_out [rows][cols] f32 -> planes, K-TILE-MAJOR: [cols / 32][3 planes][rows][32 k] bf16 (hi, mid, lo); one thread per 8 values.
+// Every workgroup of the value gradient reads the same K tile of these planes at about the same time; in the row-major form a K
+// tile is 128 pieces of 64 bytes at a stride of one row (2 or 4 KB), i.e. one L2 channel for the whole tile.  Tile-major, a K tile
+// is 24 KB of consecutive bytes spread over every channel.
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int rows, int cols, unsigned short* __restrict__ planes) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // 8-value run i: row i / (cols / 8), k = 8 * (i % (cols / 8))
+  const int runs = cols / 8;
+  if (i >= (long long)rows * runs) return;
+  const int m = (int)(i / runs), k = (int)(i % runs) * 8;
   const u32x4 v0 = *reinterpret_cast<const u32x4*>(src + i * 8), v1 = *reinterpret_cast<const u32x4*>(src + i * 8 + 4);
   u32x4 hi, mid, lo;
   split8(v0, v1, hi, mid, lo);
-  *reinterpret_cast<u32x4*>(planes + i * 8) = hi;
-  *reinterpret_cast<u32x4*>(planes + plane_elems + i * 8) = mid;
-  *reinterpret_cast<u32x4*>(planes + 2 * plane_elems + i * 8) = lo;
+  const size_t plane = (size_t)rows * 32, base = ((size_t)(k >> 5) * 3 * rows + m) * 32 + (k & 31);
+  *reinterpret_cast<u32x4*>(planes + base) = hi;
+  *reinterpret_cast<u32x4*>(planes + base + plane) = mid;
+  *reinterpret_cast<u32x4*>(planes + base + 2 * plane) = lo;
 }
 
 __device__ __forceinline__ void dma16(const void* g, void* l) {
@@ -93,12 +98,12 @@ __device__ __forceinline__ void load16_hi(u32x4& dst, const float* base, unsigne
 }
 
 constexpr int kDepth = 3;            // K tiles in flight: tile t computes while t + 1 and t + 2 travel
-constexpr int kOpsPerTile = 6 + 4;   // per wave: six DMA pieces, then four table loads (issue order = vmcnt order)
+// per wave and K tile: six DMA pieces, then 2 * NB table loads (issue order = vmcnt order)
 
 // ABL: timing-only ablations (tools/debug, wrong results unless 0): 1 no DMA after the prologue, 2 no table loads after the
 // prologue.  (A "no MFMA" variant spilled 109 registers to scratch beside the asm loads and faulted: not kept.)
-template <int ABL, bool NT>
-__global__ __launch_bounds__(256, 2) void ftv_values_kernel(const unsigned short* __restrict__ planes,  // [3][M][K] bf16
+template <int ABL, bool NT, int NB>
+__global__ __launch_bounds__(256, NB == 2 ? 2 : 1) void ftv_values_kernel(const unsigned short* __restrict__ planes,  // [K / 32][3][M][32] bf16
                                                          const float* __restrict__ weight, const uint8_t* __restrict__ bits,
                                                          float* __restrict__ out, int M, int N, int K, int F, int prio_mode) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[kDepth * kBuf];
@@ -114,8 +119,9 @@ __global__ __launch_bounds__(256, 2) void ftv_values_kernel(const unsigned short
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
+  constexpr int kBN = 64 * NB;
   const int n_base = blockIdx.x * kBN, m_base = blockIdx.y * kBM;
-  const int n_wave = n_base + 32 * wave;
+  const int n_wave = n_base + 16 * NB * wave;
   const int tiles = K / kKT;
 
   // ---- D planes by LDS-DMA.  Piece = 1 KiB = 16 rows x 64 bytes of one plane; 24 pieces per K tile, six per wave.  Lane l
@@ -129,39 +135,39 @@ __global__ __launch_bounds__(256, 2) void ftv_values_kernel(const unsigned short
     const int row = 16 * g + (lane >> 2);
     const int chunk = (lane & 3) ^ ((4 - (row >> 2)) & 3);
     const int m = m_base + row < M ? m_base + row : M - 1;
-    src_piece[i] = planes + ((size_t)plane * M + m) * K + chunk * 8;
+    src_piece[i] = planes + ((size_t)plane * M + m) * 32 + chunk * 8;  // K-tile-major planes: tile t at + t * 3 * M * 32
     dst_piece[i] = plane * kPlane + g * 1024;
   }
   // ---- table fragments straight into registers: column block j of this wave, lane (r, q) = 8 consecutive k of row
   // min(n, F - 1): two 16-byte loads, 128 contiguous bytes per table row and K tile
-  unsigned w_off[2];
+  unsigned w_off[NB];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NB; ++j) {
     const int n = n_wave + 16 * j + r;
     const int row = n < F - 1 ? n : F - 1;
     w_off[j] = (unsigned)(row * K + 8 * q) * 4u;
   }
-  u32x4 rw[kDepth][2][2];
+  u32x4 rw[kDepth][NB][2];
   auto issue = [&](int t, auto slot_tag) {  // tile t into slot t % kDepth: DMA pieces first, table loads after them
     constexpr int S = decltype(slot_tag)::value;
     if (!(ABL == 1 && t >= kDepth)) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) dma16(src_piece[i] + (size_t)t * kKT, smem + S * kBuf + dst_piece[i]);
+      for (int i = 0; i < 6; ++i) dma16(src_piece[i] + (size_t)t * (3 * 32) * M, smem + S * kBuf + dst_piece[i]);
     }
     if (!(ABL == 2 && t >= kDepth)) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NB; ++j) {
         load16<NT>(rw[S][j][0], weight, w_off[j] + (unsigned)t * (kKT * 4));
         load16_hi<NT>(rw[S][j][1], weight, w_off[j] + (unsigned)t * (kKT * 4));
       }
     }
   };
 
-  f32x4 acc[8][2];
+  f32x4 acc[8][NB];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   int a_off[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) a_off[i] = img(16 * i + r, q);
@@ -169,17 +175,26 @@ __global__ __launch_bounds__(256, 2) void ftv_values_kernel(const unsigned short
   // One K tile.
   auto step = [&](int t, auto slot_tag) {
     constexpr int S = decltype(slot_tag)::value;
-    u32x4 &w00 = rw[S][0][0], &w01 = rw[S][0][1], &w10 = rw[S][1][0], &w11 = rw[S][1][1];
     // On entry tiles t and t + 1 are in flight (t + 2 is issued below, after the barrier has freed its slot): everything of
-    // tile t must have landed, tile t + 1's ten operations may stay out.  The registers come back through the operands -- an
+    // tile t must have landed, tile t + 1's 6 + 2 NB operations may stay out.  The registers come back through the operands -- an
     // asm load's destination counts as written at the statement, so without this hand-back the compiler may reuse it before
     // the data lands (a too-large count here showed up as a memory fault: a late load landed in a register holding an address).
-    if (ABL == 1 || ABL == 2 || t + 1 >= tiles) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w00), "+v"(w01), "+v"(w10), "+v"(w11)::"memory");
-    else asm volatile("s_waitcnt vmcnt(10)" : "+v"(w00), "+v"(w01), "+v"(w10), "+v"(w11)::"memory");
-    static_assert(kOpsPerTile == 10 && kDepth == 3, "the counted wait above is one tile's operations");
-    u32x4 bw[3][2];  // [plane][column block]
-    split8(w00, w01, bw[0][0], bw[1][0], bw[2][0]);
-    split8(w10, w11, bw[0][1], bw[1][1], bw[2][1]);
+    const bool last = ABL == 1 || ABL == 2 || t + 1 >= tiles;
+    if constexpr (NB == 2) {
+      u32x4 &w00 = rw[S][0][0], &w01 = rw[S][0][1], &w10 = rw[S][1][0], &w11 = rw[S][1][1];
+      if (last) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w00), "+v"(w01), "+v"(w10), "+v"(w11)::"memory");
+      else asm volatile("s_waitcnt vmcnt(10)" : "+v"(w00), "+v"(w01), "+v"(w10), "+v"(w11)::"memory");
+    } else {
+      static_assert(NB == 2 || NB == 4, "column blocks per wave");
+      u32x4 &w00 = rw[S][0][0], &w01 = rw[S][0][1], &w10 = rw[S][1][0], &w11 = rw[S][1][1];
+      u32x4 &w20 = rw[S][2][0], &w21 = rw[S][2][1], &w30 = rw[S][3][0], &w31 = rw[S][3][1];
+      if (last) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w00), "+v"(w01), "+v"(w10), "+v"(w11), "+v"(w20), "+v"(w21), "+v"(w30), "+v"(w31)::"memory");
+      else asm volatile("s_waitcnt vmcnt(14)" : "+v"(w00), "+v"(w01), "+v"(w10), "+v"(w11), "+v"(w20), "+v"(w21), "+v"(w30), "+v"(w31)::"memory");
+    }
+    static_assert(kDepth == 3, "the counted waits above are one tile's operations: 6 + 2 NB");
+    u32x4 bw[3][NB];  // [plane][column block]
+#pragma unroll
+    for (int j = 0; j < NB; ++j) split8(rw[S][j][0], rw[S][j][1], bw[0][j], bw[1][j], bw[2][j]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave's pieces of tile t are in LDS; every wave is done with tile t - 1 (slot (t - 1) % 3)
     asm volatile("" ::: "memory");
@@ -202,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void ftv_values_kernel(const unsigned short
 #pragma unroll
       for (int s = 0; s < 6; ++s)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NB; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i & 1][pa[s]]), __builtin_bit_cast(bf16x8, bw[pb[s]][j]),
                                                               acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
@@ -224,9 +239,9 @@ __global__ __launch_bounds__(256, 2) void ftv_values_kernel(const unsigned short
   // ---- epilogue: acc[i][j][e] = C[m_base + 16 i + 4 q + e][n_wave + 16 j + r], kept where the position is active
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    unsigned char bit[2][4];
+    unsigned char bit[NB][4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int m = m_base + 16 * i + 4 * q + e, n = n_wave + 16 * j + r;
@@ -234,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void ftv_values_kernel(const unsigned short
         bit[j][e] = bits[ok ? (size_t)m * N + n : 0];
       }
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int m = m_base + 16 * i + 4 * q + e, n = n_wave + 16 * j + r;
@@ -244,35 +259,49 @@ __global__ __launch_bounds__(256, 2) void ftv_values_kernel(const unsigned short
 }
 }  // namespace
 
+namespace {
+int ftv_nb() {  // developer knob: 16-column blocks per wave (tile width 64 * NB): 4 = 128 x 256 tiles, one workgroup per CU
+  const char* e = getenv("NNUE_FTM_VAL_NB");
+  return (e && atoi(e) == 4) ? 4 : 2;
+}
+}  // namespace
+
 bool ftv_supported(int B, int F, int P, int L1) {
-  // Off by default: measured in the 224x224 step it ties the six-plane tile kernel (102.3 vs 102.8 us, + 5 us for the split
-  // pre-pass).  Read per call so that tests can switch it inside one process.
+  // Off by default: measured in the 224x224 step it ties the six-plane tile kernel.  Read per call so
+  // that tests can switch it inside one process.
   const char* e = getenv("NNUE_FTM_VAL_DMA");
   const int on = e ? atoi(e) : 0;
-  // big maps only: the 128 x 128 tiles must fill the chip, K runs in whole tiles of 32, every offset fits 31 bits
-  return on && B > 0 && L1 % kKT == 0 && P % 4 == 0 && (long long)((P + kBN - 1) / kBN) * ((B + kBM - 1) / kBM) >= 384 &&
+  // big maps only: 128-column tiles must fill the chip, K runs in whole tiles of 32, every offset fits 31 bits
+  return on && B > 0 && L1 % kKT == 0 && P % 4 == 0 && (long long)((P + 127) / 128) * ((B + kBM - 1) / kBM) >= 384 &&
          (long long)F * L1 * 4 < (1ll << 31) && (long long)B * L1 * 2 < (1ll << 31);
 }
 
 int64_t ftv_scratch_bytes(int B, int L1) { return (int64_t)3 * B * L1 * 2; }
 
+void ftv_split_planes(const float* src, int rows, int cols, void* planes, hipStream_t st) {
+  const long long count8 = (long long)rows * cols / 8;
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((count8 + 255) / 256)), dim3(256), 0, st, src, rows, cols,
+                     static_cast<unsigned short*>(planes));
+}
+
 int ftv_launch(const uint8_t* bits, const float* d_out, const float* weight, int B, int F, int P, int L1, float* d_conv_out, void* scratch,
                hipStream_t st) {
   unsigned short* planes = static_cast<unsigned short*>(scratch);
-  const long long count8 = (long long)B * L1 / 8;
-  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((count8 + 255) / 256)), dim3(256), 0, st, d_out, count8, (long long)B * L1, planes);
-  const dim3 grid((unsigned)((P + kBN - 1) / kBN), (unsigned)((B + kBM - 1) / kBM));
+  ftv_split_planes(d_out, B, L1, planes, st);
+  const int nb = ftv_nb(), bn = 64 * nb;
+  const dim3 grid((unsigned)((P + bn - 1) / bn), (unsigned)((B + kBM - 1) / kBM));
   const bool nt = (size_t)F * L1 * 4 > (64u << 20);  // a table larger than the caches is streamed once: non-temporal loads
   static const int abl = [] { const char* e = getenv("NNUE_FTM_VAL_ABL"); return e ? atoi(e) : 0; }();  // timing-only ablations
   static const int prio = [] { const char* e = getenv("NNUE_FTM_VAL_PRIO"); return e ? atoi(e) : 0; }();  // developer knob: see the kernel
-#define NNUE_FTV(A)                                                                                                                         \
-  do {                                                                                                                                      \
-    if (nt) hipLaunchKernelGGL((ftv_values_kernel<A, true>), grid, dim3(256), 0, st, planes, weight, bits, d_conv_out, B, P, L1, F, prio); \
-    else hipLaunchKernelGGL((ftv_values_kernel<A, false>), grid, dim3(256), 0, st, planes, weight, bits, d_conv_out, B, P, L1, F, prio); \
+#define NNUE_FTV(A, NBV)                                                                                                                      \
+  do {                                                                                                                                        \
+    if (nt) hipLaunchKernelGGL((ftv_values_kernel<A, true, NBV>), grid, dim3(256), 0, st, planes, weight, bits, d_conv_out, B, P, L1, F, prio); \
+    else hipLaunchKernelGGL((ftv_values_kernel<A, false, NBV>), grid, dim3(256), 0, st, planes, weight, bits, d_conv_out, B, P, L1, F, prio);   \
   } while (0)
-  if (abl == 1) NNUE_FTV(1);
-  else if (abl == 2) NNUE_FTV(2);
-  else NNUE_FTV(0);
+  if (nb == 4) NNUE_FTV(0, 4);
+  else if (abl == 1) NNUE_FTV(1, 2);
+  else if (abl == 2) NNUE_FTV(2, 2);
+  else NNUE_FTV(0, 2);
 #undef NNUE_FTV
   return NNUE_OK;
 }

@@ -80,7 +80,7 @@ def test_ftm_kernels_against_float64(hip, shape, density):
     assert only_b[0] is None and torch.equal(only_b[1], d_b)
 
 
-@pytest.mark.parametrize("shape", [(24, 64, 32, 32, 65536, 256), (130, 64, 24, 24, 30000, 128), (128, 64, 32, 32, 65536, 64)])
+@pytest.mark.parametrize("shape", [(24, 64, 32, 32, 65536, 256), (130, 64, 24, 24, 30000, 128), (128, 64, 32, 32, 65536, 512)])
 def test_value_gradient_by_lds_dma_against_float64(hip, shape, monkeypatch):
     """The optional big-map value gradient of csrc/ftv_kernels.hip (NNUE_FTM_VAL_DMA=1: d_out split once into bf16 planes in a
     workspace and staged by LDS-DMA, table fragments straight to registers): row tail, two row tiles, the F-1 clamp, and bitwise
@@ -101,9 +101,16 @@ def test_value_gradient_by_lds_dma_against_float64(hip, shape, monkeypatch):
     active = (conv_out > 0.17).reshape(b, -1)
     assert not bool(d_val.view(b, -1)[~active.to(DEV)].any())
     assert torch.equal(hip.ftm_backward_values(g(d_out), g(weight), fm), d_val)  # fixed order: reproducible
+    # the default: the six-plane tile kernel, d_out split in every workgroup, no workspace
     monkeypatch.setenv("NNUE_FTM_VAL_DMA", "0")
     assert int(hip.load().nnue_ftm_backward_values_scratch(b, f, fps * gh * gw, l1)) == 0
-    assert_close_grad(hip.ftm_backward_values(g(d_out), g(weight), fm), d_val, "tile kernel vs LDS-DMA kernel", rtol=2e-5)
+    d_tile = hip.ftm_backward_values(g(d_out), g(weight), fm)
+    assert_close_grad(d_tile.view(conv_out.shape), ref_dval, "d_conv_out (tile kernel)", rtol=2e-5)
+    # ... and the same kernel fed with the d_out planes from the workspace (NNUE_FTM_VAL_PLANES=1; measured slower, kept as a
+    # knob): the same terms in the same order, bit for bit
+    monkeypatch.setenv("NNUE_FTM_VAL_PLANES", "1")
+    assert int(hip.load().nnue_ftm_backward_values_scratch(b, f, fps * gh * gw, l1)) == (3 * b * l1 * 2 if l1 % 32 == 0 else 0)
+    assert torch.equal(hip.ftm_backward_values(g(d_out), g(weight), fm), d_tile)
 
 
 @pytest.mark.parametrize("name", MODEL_CASES)
