@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 27
+#define NNUE_HIP_ABI_VERSION 28
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -425,7 +425,7 @@ int nnue_ftm_backward_tail_rows(const float* sink, const float* d_out, int B, in
 int nnue_ftm_backward_weight_update(const uint8_t* bits, const float* d_out, int B, int F, int P, int L1,
                                     float* weight, float* momentum_rows, const float* coef,
                                     float lr, float momentum, float weight_decay, float grad_scale,
-                                    int first_step, nnue_stream_t stream);
+                                    int first_step, const float* lr_dev, nnue_stream_t stream);
 
 /* Reporting only: 1 when the product of this shape runs on the bf16 matrix unit (exact three-way split of the f32
  * operand), 0 on the f32 MFMA.  which: 0 forward, 1 stand-alone weight gradient, 2 weight-gradient tiles of the merged
@@ -537,7 +537,10 @@ int nnue_sqnorm_partials(const float* grads, int64_t count, float* partial, int 
  * coef_out != NULL: the clip coefficient c is also left in that device float.  ext_applied_elsewhere != 0 (needs
  * ext_partial and coef_out): grads[ext_lo, ext_hi) does not exist -- its producer applies the update itself afterwards
  * (nnue_ftm_backward_weight_update, reading coef_out) -- so this call neither reads that range of grads nor touches that
- * range of params / momentum_buf. */
+ * range of params / momentum_buf.
+ * lr_dev != NULL (here, in nnue_adam_step and in nnue_ftm_backward_weight_update): the learning rate is read from that device
+ * float instead of the `lr` argument -- an optimizer's lr changes between steps (a scheduler stepping param_groups, the
+ * counterpart of train.py:457-471's optimizers) without re-recording or re-capturing a step that was captured into a graph. */
 int64_t nnue_sgd_scratch(int64_t count);
 int nnue_sgd_step(float* params, float* grads, float* momentum_buf, int64_t count,
                   float lr, float momentum, float weight_decay, float max_norm, float grad_scale,
@@ -545,7 +548,7 @@ int nnue_sgd_step(float* params, float* grads, float* momentum_buf, int64_t coun
                   const float* ste_partial, int ste_chunks, int ste_fps,
                   float* ste_d_thr, float* ste_d_weight,
                   const float* ext_partial, int ext_count, int64_t ext_lo, int64_t ext_hi,
-                  float* coef_out, int ext_applied_elsewhere, nnue_stream_t stream);
+                  float* coef_out, int ext_applied_elsewhere, const float* lr_dev, nnue_stream_t stream);
 
 /* ---- input pipeline ------------------------------------------------------------------------------
  * One batch of GenericVisionDataset.__getitem__ + collate (data/datasets.py:173-195, :358-372) from a uint8
@@ -569,7 +572,7 @@ int nnue_load_batch(const uint8_t* images_u8, const int64_t* labels_all, const i
 int nnue_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int32_t* step_counter,
                    int64_t count, float lr, float beta1, float beta2, float eps, float weight_decay,
                    float max_norm, float grad_scale, float* norm_out,
-                   void* scratch, int64_t scratch_bytes, nnue_stream_t stream);
+                   void* scratch, int64_t scratch_bytes, const float* lr_dev, nnue_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -118,6 +118,7 @@ struct BwwSgdEpi {
   float lr, mom, wd, scale;
   int first_step;
   int xcd_remap;  // 1: workgroups that share an XCD (equal blockIdx % 8) take consecutive tiles
+  const float* __restrict__ lr_dev;  // when non-NULL the learning rate is read from this device float (a scheduler's hook: no re-capture)
   __device__ __forceinline__ float2 col(int) const { return make_float2(coef[0] * scale, 0.f); }
   __device__ __forceinline__ float pre(int m, int n) const { return weight[(size_t)m * L1 + n]; }
   __device__ __forceinline__ void store(int m, int n, float v, float2 c, float w, int) const {
@@ -127,7 +128,7 @@ struct BwwSgdEpi {
       gi = first_step ? gi : fmaf(mom, momentum[i], gi);
       momentum[i] = gi;
     }
-    weight[i] = w - lr * gi;
+    weight[i] = w - (lr_dev ? lr_dev[0] : lr) * gi;
   }
 };
 
@@ -385,6 +386,7 @@ __device__ __forceinline__ void rmw_tile(float* __restrict__ smem, const Epi& ep
   const int tid = threadIdx.x, lane = tid & 63;
   const int r = lane & 15, q = lane >> 4;
   const float gs = epi.coef[0] * epi.scale;
+  const float lr = epi.lr_dev ? epi.lr_dev[0] : epi.lr;
   float4 w[PER], mo[PER];
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
@@ -419,7 +421,7 @@ __device__ __forceinline__ void rmw_tile(float* __restrict__ smem, const Epi& ep
         }
         nt_store4(epi.momentum + i, g);
       }
-      nt_store4(epi.weight + i, make_float4(w[u].x - epi.lr * g.x, w[u].y - epi.lr * g.y, w[u].z - epi.lr * g.z, w[u].w - epi.lr * g.w));
+      nt_store4(epi.weight + i, make_float4(w[u].x - lr * g.x, w[u].y - lr * g.y, w[u].z - lr * g.z, w[u].w - lr * g.w));
     }
   }
 }
@@ -2138,7 +2140,7 @@ extern "C" int nnue_ftm_backward_tail_rows(const float* sink, const float* d_out
 
 extern "C" int nnue_ftm_backward_weight_update(const uint8_t* bits, const float* d_out, int B, int F, int P, int L1, float* weight,
                                                float* momentum_rows, const float* coef, float lr, float momentum, float weight_decay,
-                                               float grad_scale, int first_step, nnue_stream_t stream) {
+                                               float grad_scale, int first_step, const float* lr_dev, nnue_stream_t stream) {
   NNUE_REQUIRE(bits && d_out && weight && coef, NNUE_E_ARG, "nnue_ftm_backward_weight_update: null pointer");
   NNUE_REQUIRE(momentum == 0.0f || momentum_rows, NNUE_E_ARG, "nnue_ftm_backward_weight_update: momentum %g needs the momentum rows", momentum);
   NNUE_REQUIRE(shape_ok(B, F, P, L1), NNUE_E_ARG, "nnue_ftm_backward_weight_update: B=%d F=%d P=%d L1=%d out of range", B, F, P, L1);
@@ -2156,7 +2158,7 @@ extern "C" int nnue_ftm_backward_weight_update(const uint8_t* bits, const float*
   static const int xcd = env_int("NNUE_FTM_XCD_REMAP", 1);  // developer knob
   launch<false, false>(static_cast<hipStream_t>(stream), s, Mat{bits, (unsigned)((size_t)B * P), P, kIntMax, kIntMax},
                        Mat{d_out, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, kIntMax},
-                       BwwSgdEpi{weight, momentum == 0.0f ? nullptr : momentum_rows, coef, L1, lr, momentum, weight_decay, grad_scale, first_step, xcd},
+                       BwwSgdEpi{weight, momentum == 0.0f ? nullptr : momentum_rows, coef, L1, lr, momentum, weight_decay, grad_scale, first_step, xcd, lr_dev},
                        direct, L1, B);
   return nnue_launch_status("nnue_ftm_backward_weight_update");
 }

@@ -185,9 +185,11 @@ __global__ __launch_bounds__(256) void sgd_apply_kernel(float* __restrict__ p, c
                                                         float wd, float max_norm, float scale, int first_step,
                                                         const float* __restrict__ partial, int nparts,
                                                         float* __restrict__ norm_out, const float* __restrict__ ext_partial,
-                                                        int ext_count, float* __restrict__ coef_out, int64_t skip_lo, int64_t skip_hi) {
+                                                        int ext_count, float* __restrict__ coef_out, int64_t skip_lo, int64_t skip_hi,
+                                                        const float* __restrict__ lr_dev) {
   __shared__ double red[4];
   __shared__ float coef_s;
+  if (lr_dev) lr = lr_dev[0];  // the learning rate as a device scalar: a scheduler changes it without re-capturing the step
   // The first kPre passes of this thread's share are requested BEFORE the norm is re-derived: after a kernel boundary
   // both the partials and the parameters are first touches (~2 us each from a cold L2), and the two waits would
   // otherwise run one after the other.  Unconditional loads from clamped indices; results used only where valid.
@@ -258,9 +260,11 @@ __global__ __launch_bounds__(256) void sgd_apply_vec_kernel(float* __restrict__ 
                                                             int64_t count, float lr, float momentum, float wd, float max_norm, float scale,
                                                             int first_step, const float* __restrict__ partial, int nparts,
                                                             float* __restrict__ norm_out, const float* __restrict__ ext_partial, int ext_count,
-                                                            float* __restrict__ coef_out, int64_t skip_lo, int64_t skip_hi) {
+                                                            float* __restrict__ coef_out, int64_t skip_lo, int64_t skip_hi,
+                                                            const float* __restrict__ lr_dev) {
   __shared__ double red[4];
   __shared__ float coef_s;
+  if (lr_dev) lr = lr_dev[0];
   constexpr int kPre = 2;
   const int64_t stride = (int64_t)gridDim.x * 256;
   const int64_t hole4 = (skip_hi - skip_lo) >> 2, lo4 = skip_lo >> 2, live4 = (count >> 2) - hole4;
@@ -339,9 +343,10 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(float* __restrict__ p, 
                                                          float lr, float beta1, float beta2, float eps, float wd,
                                                          float max_norm, float scale, const int* __restrict__ step_counter,
                                                          const float* __restrict__ partial, int nparts,
-                                                         float* __restrict__ norm_out) {
+                                                         float* __restrict__ norm_out, const float* __restrict__ lr_dev) {
   __shared__ double red[4];
   __shared__ float coef_s;
+  if (lr_dev) lr = lr_dev[0];
   double acc = 0.0;
   for (int i = threadIdx.x; i < nparts; i += 256) acc += (double)partial[i];
 #pragma unroll
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(float* __restrict__ p, 
 
 extern "C" int nnue_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int32_t* step_counter, int64_t count,
                               float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm, float grad_scale,
-                              float* norm_out, void* scratch, int64_t scratch_bytes, nnue_stream_t stream) {
+                              float* norm_out, void* scratch, int64_t scratch_bytes, const float* lr_dev, nnue_stream_t stream) {
   NNUE_REQUIRE(params && grads && exp_avg && exp_avg_sq && step_counter && scratch, NNUE_E_ARG, "nnue_adam_step: null pointer");
   NNUE_REQUIRE(count > 0, NNUE_E_ARG, "nnue_adam_step: count must be positive");
   NNUE_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps > 0.f, NNUE_E_ARG,
@@ -388,7 +393,7 @@ extern "C" int nnue_adam_step(float* params, float* grads, float* exp_avg, float
   int blocks = (int)((count + 1023) / 1024);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_apply_kernel, dim3(blocks), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps,
-                     weight_decay, max_norm, grad_scale, step_counter, partial, kNormBlocks, norm_out);
+                     weight_decay, max_norm, grad_scale, step_counter, partial, kNormBlocks, norm_out, lr_dev);
   return nnue_launch_status("nnue_adam_step");
 }
 
@@ -423,7 +428,7 @@ extern "C" int nnue_sgd_step(float* params, float* grads, float* momentum_buf, i
                              float weight_decay, float max_norm, float grad_scale, int first_step, float* norm_out,
                              void* scratch, int64_t scratch_bytes, const float* ste_partial, int ste_chunks, int ste_fps,
                              float* ste_d_thr, float* ste_d_weight, const float* ext_partial, int ext_count, int64_t ext_lo,
-                             int64_t ext_hi, float* coef_out, int ext_applied_elsewhere, nnue_stream_t stream) {
+                             int64_t ext_hi, float* coef_out, int ext_applied_elsewhere, const float* lr_dev, nnue_stream_t stream) {
   NNUE_REQUIRE(params && grads && scratch, NNUE_E_ARG, "nnue_sgd_step: null pointer");
   NNUE_REQUIRE(count > 0, NNUE_E_ARG, "nnue_sgd_step: count must be positive");
   NNUE_REQUIRE(momentum == 0.0f || momentum_buf, NNUE_E_ARG, "nnue_sgd_step: momentum %g needs a momentum buffer", momentum);
@@ -479,11 +484,11 @@ extern "C" int nnue_sgd_step(float* params, float* grads, float* momentum_buf, i
     int vb = (int)((live / 4 + 511) / 512);  // two float4 passes per thread
     vb = vb < 1 ? 1 : (vb > 2048 ? 2048 : vb);
     hipLaunchKernelGGL(sgd_apply_vec_kernel, dim3(vb), dim3(256), 0, s, params, grads, mom, count, lr, momentum, weight_decay, max_norm, grad_scale,
-                       first_step, partial, nparts, norm_out, ext_partial, ext_count, coef_out, skip_lo, skip_hi);
+                       first_step, partial, nparts, norm_out, ext_partial, ext_count, coef_out, skip_lo, skip_hi, lr_dev);
     return nnue_launch_status("nnue_sgd_step");
   }
   hipLaunchKernelGGL(sgd_apply_kernel, dim3(blocks), dim3(256), 0, s, params, grads, mom, count, lr, momentum, weight_decay, max_norm, grad_scale,
-                     first_step, partial, nparts, norm_out, ext_partial, ext_count, coef_out, skip_lo, skip_hi);
+                     first_step, partial, nparts, norm_out, ext_partial, ext_count, coef_out, skip_lo, skip_hi, lr_dev);
   return nnue_launch_status("nnue_sgd_step");
 }
 

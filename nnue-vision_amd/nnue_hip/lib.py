@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -114,9 +114,9 @@ SIGNATURES = {
     "nnue_engine_evaluate_logits": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_i64, _c_p]),
     "nnue_sgd_scratch": (_c_i64, [_c_i64]),
     "nnue_adam_step": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f,
-                                _c_p, _c_p, _c_i64, _c_p]),
+                                _c_p, _c_p, _c_i64, _c_p, _c_p]),
     "nnue_sgd_step": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_int,
-                               _c_p, _c_p, _c_i64, _c_p, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_i64, _c_i64, _c_p, _c_int, _c_p]),
+                               _c_p, _c_p, _c_i64, _c_p, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_i64, _c_i64, _c_p, _c_int, _c_p, _c_p]),
     "nnue_ftm_uses_bf16": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int]),
     "nnue_sqnorm_partials": (_c_int, [_c_p, _c_i64, _c_p, _c_int, _c_p]),
     "nnue_dp_factor_chunk_bytes": (_c_i64, [_c_int, _c_int, _c_int, _c_i64]),
@@ -128,7 +128,7 @@ SIGNATURES = {
     "nnue_ftm_gram_sqnorm": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
     "nnue_ftm_backward_tail_rows": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
     "nnue_ftm_backward_weight_update": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_f, _c_f, _c_f, _c_f,
-                                                 _c_int, _c_p]),
+                                                 _c_int, _c_p, _c_p]),
 }
 
 _lib: Optional[ctypes.CDLL] = None
@@ -1024,15 +1024,16 @@ def ftm_backward_tail_rows(d_out: torch.Tensor, fm: "FeatureMatrix", d_weight: t
 
 def ftm_backward_weight_update(d_out: torch.Tensor, fm: "FeatureMatrix", weight: torch.Tensor, momentum_rows: Optional[torch.Tensor],
                                coef: torch.Tensor, lr: float, momentum: float, weight_decay: float, grad_scale: float,
-                               first_step: bool) -> None:
-    """weight rows [0, direct) <- SGD update with d_W = A^T d_out formed and consumed in the product's epilogue."""
+                               first_step: bool, lr_dev: Optional[torch.Tensor] = None) -> None:
+    """weight rows [0, direct) <- SGD update with d_W = A^T d_out formed and consumed in the product's epilogue.
+    lr_dev (device float32 scalar): the learning rate is read from it instead of `lr`."""
     d_out = _need(d_out, torch.float32, "d_out")
     b, l1 = d_out.shape
     weight = _need(weight, torch.float32, "input.weight", (fm.num_rows, l1))
     _need(coef, torch.float32, "clip coefficient")
     _call("nnue_ftm_backward_weight_update", fm.bits.data_ptr(), d_out.data_ptr(), b, fm.num_rows, fm.positions, l1, weight.data_ptr(),
           _ptr(momentum_rows), coef.data_ptr(), float(lr), float(momentum), float(weight_decay), float(grad_scale),
-          int(bool(first_step)), _stream(d_out))
+          int(bool(first_step)), _ptr(lr_dev), _stream(d_out))
 
 
 class FactorExchange:
@@ -1077,9 +1078,11 @@ class FactorExchange:
 def sgd_step(params: torch.Tensor, grads: torch.Tensor, momentum_buf: Optional[torch.Tensor], lr: float,
              momentum: float, weight_decay: float, max_norm: float, grad_scale: float, first_step: bool,
              norm_out: Optional[torch.Tensor], scratch: torch.Tensor, ste=None, ext=None,
-             coef_out: Optional[torch.Tensor] = None, ext_applied_elsewhere: bool = False) -> None:
+             coef_out: Optional[torch.Tensor] = None, ext_applied_elsewhere: bool = False,
+             lr_dev: Optional[torch.Tensor] = None) -> None:
     """ste = (partial scratch of ste_conv_backward(stages=1), chunks, fps, d_thr, d_weight): the deferred second stage
-    runs inside the norm launch; d_thr / d_weight must be the first elements of `grads`."""
+    runs inside the norm launch; d_thr / d_weight must be the first elements of `grads`.  lr_dev (device float32 scalar): the
+    learning rate is read from it instead of `lr` (changes between steps need no re-recording / re-capture)."""
     params = _need(params, torch.float32, "flat params")
     grads = _need(grads, torch.float32, "flat grads", tuple(params.shape))
     if momentum_buf is not None:
@@ -1094,13 +1097,13 @@ def sgd_step(params: torch.Tensor, grads: torch.Tensor, momentum_buf: Optional[t
     _call("nnue_sgd_step", params.data_ptr(), grads.data_ptr(), _ptr(momentum_buf), params.numel(), float(lr),
           float(momentum), float(weight_decay), float(max_norm), float(grad_scale), int(bool(first_step)),
           _ptr(norm_out), scratch.data_ptr(), scratch.numel(), *ste_args, *ext_args, _ptr(coef_out), int(bool(ext_applied_elsewhere)),
-          _stream(params))
+          _ptr(lr_dev), _stream(params))
 
 
 def adam_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
               step_counter: torch.Tensor, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
               max_norm: float = 0.0, grad_scale: float = 1.0, norm_out: Optional[torch.Tensor] = None,
-              scratch: Optional[torch.Tensor] = None) -> None:
+              scratch: Optional[torch.Tensor] = None, lr_dev: Optional[torch.Tensor] = None) -> None:
     params = _need(params, torch.float32, "flat params")
     shape = tuple(params.shape)
     grads = _need(grads, torch.float32, "flat grads", shape)
@@ -1111,7 +1114,7 @@ def adam_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, 
         scratch = torch.empty((sgd_scratch_bytes(params.numel()),), dtype=torch.uint8, device=params.device)
     _call("nnue_adam_step", params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
           step_counter.data_ptr(), params.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
-          float(max_norm), float(grad_scale), _ptr(norm_out), scratch.data_ptr(), scratch.numel(), _stream(params))
+          float(max_norm), float(grad_scale), _ptr(norm_out), scratch.data_ptr(), scratch.numel(), _ptr(lr_dev), _stream(params))
 
 
 def load_batch(images_u8: torch.Tensor, labels_all: torch.Tensor, indices: torch.Tensor, augment: bool, seed: int, step: int,

@@ -281,6 +281,9 @@ class NnueTrainer:
         # round trip between the local kernels, the exchange and the update.  NNUE_DP_CAPTURE=0 keeps the eager collective.
         self.capture_collectives = (self.dp.collectives and use_graph and self.dp.backend == "nccl" and self.dp.buckets == 1
                                     and os.environ.get("NNUE_DP_CAPTURE", "1") != "0")
+        # the learning rate lives in a device scalar the optimizer kernels read: ``trainer.lr = x`` (a scheduler's hook) is one
+        # tiny fill, the recorded plans and captured graphs stay valid (the other hyper-parameters are constants of the plans)
+        self.lr_dev = torch.full((1,), float(lr), **f32)
         self.steps_done = 0
         self.use_graph = use_graph
         self._g_local, self._g_update = {}, None
@@ -347,11 +350,17 @@ class NnueTrainer:
             self.ft_rider = self.cls_scratch[o_x:o_x + rows * self.L1 * 4].view(torch.float32).view(rows, self.L1)
 
     # ------------------------------------------------------------------ hyper-parameters
-    # The recorded update plan (and every graph captured from it) carries lr, momentum, weight decay and the clip norm
-    # as constants, so changing one re-records the update plan and drops the graphs that contain it; the local
-    # (forward/backward) plan is untouched.  ``trainer.lr = x`` and ``trainer.set_lr(x)`` are the same thing.
+    # The learning rate is a device scalar (``lr_dev``) every optimizer kernel reads: changing it costs one fill and keeps
+    # every plan and graph -- per-step schedules are fine; with ranks every rank must set the same value.  Momentum, weight
+    # decay and the clip norm are constants of the recorded update plan (and of every graph captured from it): changing one
+    # re-records that plan and drops the graphs that contain it; the local (forward/backward) plan is untouched.
+    # ``trainer.lr = x`` and ``trainer.set_lr(x)`` are the same thing.
     def _set_hyper(self, key: str, value: float) -> None:
         if self._hyper[key] == value:
+            return
+        if key == "lr":
+            self._hyper[key] = value
+            self.lr_dev.fill_(value)
             return
         if key == "momentum" and self.optimizer == "sgd" and bool(value) != (self.flat_momentum is not None):
             raise ValueError("momentum cannot be switched on or off after construction (the buffer layout is fixed)")
@@ -479,7 +488,7 @@ class NnueTrainer:
         if self.optimizer == "adam":
             lib.adam_step(self.flat_params, self.flat_grads, self.flat_exp_avg, self.flat_exp_avg_sq, self.adam_step_count,
                           self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm, scale, self.grad_norm,
-                          self.sgd_scratch)
+                          self.sgd_scratch, lr_dev=self.lr_dev)
         else:
             ste = ((self.ste_scratch, self.ste_chunks, self.fps, self.g["visual_threshold"], self.g["conv.weight"])
                    if self.defer_ste else None)
@@ -487,12 +496,12 @@ class NnueTrainer:
                          self.max_grad_norm, scale, first, self.grad_norm, self.sgd_scratch, ste=ste,
                          ext=(self.sq_partial, *self.sq_range) if self.sq_partial is not None else None,
                          coef_out=self.clip_coef if self.fuse_table_update else None,
-                         ext_applied_elsewhere=self.fuse_table_update)
+                         ext_applied_elsewhere=self.fuse_table_update, lr_dev=self.lr_dev)
             if self.fuse_table_update:
                 lo, hi = self.sq_range
                 mom = self.flat_momentum[lo:hi] if self.flat_momentum is not None else None
                 lib.ftm_backward_weight_update(self.d_ft, self.fm, self.p["input.weight"], mom, self.clip_coef, self.lr, self.momentum,
-                                               self.weight_decay, scale, first)
+                                               self.weight_decay, scale, first, lr_dev=self.lr_dev)
 
     def _exchange_and_update(self, first: bool, grad_scale: Optional[float] = None) -> None:
         """Everything after the local kernels of a data-parallel step, as launches on the current stream: the gradient
@@ -505,11 +514,11 @@ class NnueTrainer:
             lib.ftm_gram_sqnorm(fx.g_fm, fx.g_dft, self.gram, self.sq_partial)
             lib.sgd_step(self.flat_params, self.flat_grads, self.flat_momentum, self.lr, self.momentum, self.weight_decay,
                          self.max_grad_norm, scale, first, self.grad_norm, self.sgd_scratch, ext=(self.sq_partial, *self.sq_range),
-                         coef_out=self.clip_coef, ext_applied_elsewhere=True)
+                         coef_out=self.clip_coef, ext_applied_elsewhere=True, lr_dev=self.lr_dev)
             lo, hi = self.sq_range
             mom = self.flat_momentum[lo:hi] if self.flat_momentum is not None else None
             lib.ftm_backward_weight_update(fx.g_dft, fx.g_fm, self.p["input.weight"], mom, self.clip_coef, self.lr, self.momentum,
-                                           self.weight_decay, scale, first)
+                                           self.weight_decay, scale, first, lr_dev=self.lr_dev)
             return
         if not self.sharded_update:
             self.dp.allreduce_sum(self.flat_grads, async_op=False)
@@ -522,7 +531,7 @@ class NnueTrainer:
         dp.all_gather(self.all_partials, self.local_partials)  # rank-major, fixed order: every rank forms the identical norm
         mom = dp.shard_of(self.flat_momentum) if self.flat_momentum is not None else None
         lib.sgd_step(dp.shard_of(self.flat_params), self.grad_shard, mom, self.lr, self.momentum, self.weight_decay, self.max_grad_norm,
-                     scale, first, self.grad_norm, self.sgd_scratch, ext=(self.all_partials, 0, self.grad_shard.numel()))
+                     scale, first, self.grad_norm, self.sgd_scratch, ext=(self.all_partials, 0, self.grad_shard.numel()), lr_dev=self.lr_dev)
         dp.all_gather(self.flat_params, dp.shard_of(self.flat_params))
 
     def _optimizer_buffers(self):

@@ -55,12 +55,12 @@ def test_argument_validation_returns_codes_without_launching():
     assert L.nnue_ft_backward_weight(p, p, 100, 2, 10, 256, p, p, None) == -2
     assert L.nnue_ft_prepare(p, p, 128, 4, 10, p, p, p, p, p, 64, None) == -2
     # scratch too small -> NNUE_E_SCRATCH
-    assert L.nnue_sgd_step(p, p, p, 1000, 0.1, 0.9, 0.0, 1.0, 1.0, 1, None, p, 4, None, 0, 0, None, None, None, 0, 0, 0, None, 0, None) == -4
+    assert L.nnue_sgd_step(p, p, p, 1000, 0.1, 0.9, 0.0, 1.0, 1.0, 1, None, p, 4, None, 0, 0, None, None, None, 0, 0, 0, None, 0, None, None) == -4
     assert L.nnue_classifier_forward(p, 1, p, p, p, p, p, p, 0.0, 512, 1024, 128, 32, 10, p, p, p, p, 16, None) == -4
     # odd L1 with the pairwise block
     assert L.nnue_classifier_forward(p, 1, p, p, p, p, p, p, 0.0, 2, 7, 4, 4, 3, p, p, p, p, 1 << 20, None) == -2
     # momentum without a buffer
-    assert L.nnue_sgd_step(p, p, 0, 10, 0.1, 0.9, 0.0, 1.0, 1.0, 1, None, p, 1 << 20, None, 0, 0, None, None, None, 0, 0, 0, None, 0, None) == -1
+    assert L.nnue_sgd_step(p, p, 0, 10, 0.1, 0.9, 0.0, 1.0, 1.0, 1, None, p, 1 << 20, None, 0, 0, None, None, None, 0, 0, 0, None, 0, None, None) == -1
 
 
 def test_scratch_queries():

@@ -204,3 +204,50 @@ def test_step_many_is_the_same_steps_in_one_graph(shape):
     assert torch.equal(tr.flat_momentum, ref.flat_momentum)
     with pytest.raises(ValueError):
         tr.step_many((0, 3))
+
+
+@pytest.mark.parametrize("optimizer", ("sgd", "adam"))
+def test_learning_rate_schedule_without_recapture(optimizer):
+    """A per-step learning-rate schedule (``trainer.lr = x`` before every step): the rate is a device scalar the optimizer
+    kernels read, so the recorded plans and the captured graphs -- single steps and a step group -- stay as they are, and
+    the trajectory equals the oracle's with the same schedule (train.py:457-471's optimizers with a scheduler on top)."""
+    import nnue_oracle as orc
+    z = load_npz("step_c1arch.npz")
+    cfg = opt = json.loads(str(z["cfg"]))
+    params = {k[7:]: torch.from_numpy(v) for k, v in z.items() if k.startswith("state0/")}
+    images = [torch.from_numpy(z[f"images{s % 3}"]) for s in range(6)]
+    labels = [torch.from_numpy(z[f"labels{s % 3}"]).long() for s in range(6)]
+    lrs = [opt["lr"], opt["lr"] * 0.5, opt["lr"] * 2.0, opt["lr"] * 0.25, opt["lr"] * 1.5, opt["lr"] * 0.1]
+    model = build(cfg, params)
+    tr = NnueTrainer(model, images[0].shape[0], tuple(images[0].shape[2:]), lr=lrs[0], momentum=opt["momentum"],
+                     weight_decay=opt["weight_decay"], max_grad_norm=opt["max_grad_norm"], use_graph=True, input_slots=2,
+                     optimizer=optimizer)
+    ref = {k: v.clone() for k, v in params.items()}
+    state = {}
+    graphs_after_warmup = None
+    for s in range(4):  # single steps: plan, graphs, then replays with a new rate each time
+        tr.lr = lrs[s]
+        assert tr.lr == lrs[s] and float(tr.lr_dev) == pytest.approx(lrs[s])
+        tr.step(images[s].to(DEV), labels[s].to(DEV), slot=s % 2)
+        _, _, grads, _ = orc.loss_and_grads_explicit(ref, images[s], labels[s], cfg["stride"])
+        if optimizer == "sgd":
+            orc.sgd_step(ref, grads, state, lrs[s], opt["momentum"], opt["weight_decay"], opt["max_grad_norm"])
+        else:
+            orc.adam_step(ref, grads, state, lrs[s], weight_decay=opt["weight_decay"], max_grad_norm=opt["max_grad_norm"])
+        if s == 2:
+            graphs_after_warmup = set(tr._g_local)
+    assert set(tr._g_local) == graphs_after_warmup, "changing the learning rate must not drop or add graphs"
+    # a step group replayed twice with two different rates: the same graph object both times
+    for s in (4, 5):
+        tr.inputs[0][0].copy_(images[s]); tr.inputs[0][1].copy_(labels[s])
+        tr.lr = lrs[s]
+        tr.step_many((0,))
+        _, _, grads, _ = orc.loss_and_grads_explicit(ref, images[s], labels[s], cfg["stride"])
+        if optimizer == "sgd":
+            orc.sgd_step(ref, grads, state, lrs[s], opt["momentum"], opt["weight_decay"], opt["max_grad_norm"])
+        else:
+            orc.adam_step(ref, grads, state, lrs[s], weight_decay=opt["weight_decay"], max_grad_norm=opt["max_grad_norm"])
+    assert sum(1 for k in tr._g_local if k[1] == "many") == 1
+    torch.cuda.synchronize()
+    for k in orc.TRAINABLE_KEYS:
+        assert_close_grad(tr.p[k], ref[k], f"{optimizer} {k} after six steps of a schedule", rtol=5e-4)
