@@ -172,7 +172,8 @@ def test_first_step_on_another_slot_leaves_slot_zero_alone_and_lr_changes_take_e
 @pytest.mark.parametrize("shape", ("small", "buckets"))
 def test_step_many_is_the_same_steps_in_one_graph(shape):
     """step_many((s0, s1, ...)) replays the kernels of step(slot=s0), step(slot=s1), ... as one hipGraph: bitwise the same
-    parameters, momentum and per-step losses; a learning-rate change drops the captured graph."""
+    parameters, momentum and per-step losses; a learning-rate change keeps the captured graph (device scalar), a change of
+    another hyper-parameter drops it."""
     kw = dict(num_ls_buckets=4, clip_activations=1.0) if shape == "buckets" else {}
     torch.manual_seed(0)
     model = nnue.NNUE(nnue.GridFeatureSet(10, 8), 256, 32, 16, num_classes=10, **kw).to(DEV)
@@ -196,6 +197,11 @@ def test_step_many_is_the_same_steps_in_one_graph(shape):
         assert torch.equal(got, want), (rep, got, want)
     assert (order, "many") in tr._g_local and tr.steps_done == ref.steps_done == 12
     tr.lr = ref.lr = 0.2
+    assert (order, "many") in tr._g_local  # the rate is read from a device scalar: nothing is re-recorded
+    got = tr.step_many(order).clone()
+    want = torch.stack([ref.step(slot=s).clone() for s in order])
+    assert torch.equal(got, want)
+    tr.weight_decay = ref.weight_decay = 3e-4  # a constant of the recorded update plan
     assert (order, "many") not in tr._g_local
     got = tr.step_many(order).clone()
     want = torch.stack([ref.step(slot=s).clone() for s in order])
