@@ -42,7 +42,6 @@ struct Mat {
   const void* p;   // float elements, or bytes for the binary map (operand A of forward / weight gradient)
   unsigned bytes;  // window of valid rows, in bytes (< 2^31)
   int ld, clamp, inner_k;
-  int krot = 0;  // (operand A only) != 0: the K loop of a tile starts at a tile-dependent K tile and wraps around (see gemm_tile)
 };
 using u32x4 = __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned;
 
@@ -504,19 +503,11 @@ __device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& m
 
   FusedL1Pre<Epi::kFusedL1 ? BM : 32> l1pre;
   if constexpr (Epi::kFusedL1) fused_l1_prefetch<BM>(epi, l1pre, m_base, tile_n, m0, n0, r, q, wave);
-  // K rotation (ma.krot): every workgroup of a launch walks the same K tiles of the same shared operands in the same order and
-  // at the same time, i.e. the same few 256-byte columns of 4 KB rows -- the same L2 channels -- for everybody; with the rotation
-  // tile t starts at K tile (5 t) mod n and wraps, so the launch spreads over all columns at any moment.  Another fixed summation
-  // order: deterministic, not bitwise the unrotated one.
-  const int n_kt = (k_hi - k_lo + BK - 1) / BK;
-  const int rot = ma.krot ? (tile * 5 + ks) % n_kt : 0;
-  auto k_of = [&](int it) {
-    int j = it + rot;
-    j = j >= n_kt ? j - n_kt : j;
-    return k_lo + j * BK;
-  };
-  fetch(k_of(0));
-  for (int it = 0; it < n_kt; ++it) {
+  // (Rotating the K loop per tile -- tile t starts at K tile (5 t) mod n and wraps, so that the workgroups of a launch do not all
+  // walk the same 256-byte columns of the shared operands at the same time -- was measured at the CIFAR shapes and changes nothing:
+  // forward 18.1 vs 18.2 us, merged backward 25.7 vs 25.4 us; profiles/r03n_krot_ab.txt.)
+  fetch(k_lo);
+  for (int k0 = k_lo; k0 < k_hi; k0 += BK) {
 #pragma unroll
     for (int i = 0; i < AG; ++i) *reinterpret_cast<float4*>(&As[AKC ? kc(a_row(i), a_k(i)) : a_k(i) * LDA + a_row(i)]) = widen<AU8>(ra[i]);
 #pragma unroll
@@ -530,7 +521,7 @@ __device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& m
       *reinterpret_cast<float4*>(&Bs[BKC ? kc(b_row(i), b_k(i)) : b_k(i) * LDB + b_row(i)]) = v;
     }
     __syncthreads();
-    if (it + 1 < n_kt) fetch(k_of(it + 1));
+    if (k0 + BK < k_hi) fetch(k0 + BK);
     float4 a[2][TM], b[2][TN];
     frags(0, a[0], b[0]);
 #pragma unroll
@@ -2003,8 +1994,7 @@ int ftm_backward_impl(const uint8_t* bits, const float* sink, const float* d_out
     return rc != NNUE_OK ? rc : nnue_ftm_backward_values(bits, d_out, weight, B, F, P, L1, d_conv_out, stream);
   }
   const Mat wa{bits, (unsigned)((size_t)B * P), P, kIntMax, kIntMax}, wb{d_out, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, kIntMax};
-  static const int krot = env_int("NNUE_FTM_KROT", 0);  // developer knob: K rotation of the f32 value tiles (gemm_tile)
-  const Mat va{d_out, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, L1, krot}, vb{weight, (unsigned)((size_t)F * L1 * 4), L1, F - 1, kIntMax};
+  const Mat va{d_out, (unsigned)((size_t)B * L1 * 4), L1, kIntMax, L1}, vb{weight, (unsigned)((size_t)F * L1 * 4), L1, F - 1, kIntMax};
   const BwwEpi we{d_weight, L1, sq_partial};
   const ValEpi ve{bits, d_conv_out, P};
   const TailRows t = tail_rows(d_out, sink, B, L1, direct, F, d_weight, d_bias);
@@ -2080,8 +2070,7 @@ extern "C" int nnue_ftm_forward_l1(const uint8_t* bits, const float* sink, const
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int direct = (F - 1 < P) ? F - 1 : P;
   const Shape s = plan(B, L1, direct, true, true, true);
-  static const int krot = env_int("NNUE_FTM_KROT", 0);  // developer knob: K rotation of the f32 tiles (gemm_tile)
-  const Mat ma{bits, (unsigned)((size_t)B * P), P, kIntMax, kIntMax, krot}, mb{weight, (unsigned)((size_t)direct * L1 * 4), L1, kIntMax, kIntMax};
+  const Mat ma{bits, (unsigned)((size_t)B * P), P, kIntMax, kIntMax}, mb{weight, (unsigned)((size_t)direct * L1 * 4), L1, kIntMax, kIntMax};
   const FwdL1Epi epi{bias, weight + (size_t)(F - 1) * L1, sink, out, w1, part, B, L1, L2, L1 / 2};
   const dim3 grid((unsigned)(s.tiles_m * s.tiles_n));
   if (s.cfg == 0) hipLaunchKernelGGL((ftm_forward_l1_kernel<32, 128>), grid, dim3(256), 0, st, ma, mb, epi, B, L1, direct, s.tiles_n);
