@@ -66,7 +66,7 @@ def parse():
     ap.add_argument("--steps-per-graph", type=int, default=0,
                     help="consecutive steps (each on the next input slot) replayed as one hipGraph (NnueTrainer.step_many); "
                          "steps left over after the whole groups run as single-step graphs; 1 = one graph launch per step; "
-                         "0 (default) = the group size in 5..16 that leaves the fewest single steps for --steps")
+                         "0 (default) = the group size in 5..32 that leaves the fewest single steps for --steps")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather-compare", action="store_true",
@@ -235,7 +235,7 @@ def main():
     # capture one hipGraph per input slot (with the collective inside when there are ranks)
     S = args.steps_per_graph
     if S <= 0:  # fewest left-over single steps, then the larger group
-        S = min(range(5, 17), key=lambda g: (args.steps % g, -g)) if args.steps >= 5 else 1
+        S = min(range(5, 33), key=lambda g: (args.steps % g, -g)) if args.steps >= 5 else 1
 
     def run_steps(tr, n):
         """n optimizer steps, step i on input slot i % SLOTS; whole groups of S steps as one graph replay."""

@@ -534,6 +534,16 @@ class NnueTrainer:
                      scale, first, self.grad_norm, self.sgd_scratch, ext=(self.all_partials, 0, self.grad_shard.numel()), lr_dev=self.lr_dev)
         dp.all_gather(self.flat_params, dp.shard_of(self.flat_params))
 
+    def _ranks_agree(self, ok: bool) -> bool:
+        """True only when `ok` holds on EVERY rank (an eager MIN all-reduce; every rank reaches it at the same step).  A step
+        graph with the collective inside must exist on all ranks or on none: a rank that replays while another issues the
+        eager collective would pair different operations."""
+        if self.dp.world <= 1:
+            return ok
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.dev if self.dp.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.dp.group)
+        return bool(int(flag.item()))
+
     def _optimizer_buffers(self):
         return [t for t in (self.flat_momentum, self.flat_exp_avg, self.flat_exp_avg_sq, self.adam_step_count) if t is not None]
 
@@ -687,13 +697,17 @@ class NnueTrainer:
                 def full_dp(st):
                     self._run_local(slot, "all", st, branch=False)
                     self._exchange_and_update(False)
+                captured = True
                 try:
                     self._g_local[(slot, "full_dp")] = self._capture(full_dp)
                 except RuntimeError as exc:  # a stack that cannot capture its collectives: keep them eager from here on
                     import warnings
                     warnings.warn(f"collectives could not be captured into the step graph ({exc}); using the eager collective")
-                    self.capture_collectives = False
+                    captured = False
                     torch.cuda.synchronize(self.dev)
+                if not self._ranks_agree(captured):  # all ranks or none
+                    self._g_local.pop((slot, "full_dp"), None)
+                    self.capture_collectives = False
             if self.capture_collectives:
                 self._g_local[(slot, "full_dp")].replay()
                 self.steps_done += 1
@@ -772,6 +786,7 @@ class NnueTrainer:
                         self._exchange_and_update(False)
                     else:
                         lib.run_plan(upd, st.cuda_stream)
+            captured = True
             try:
                 self._g_local[(slots, "many")] = (self._capture(many), ring)
             except RuntimeError as exc:
@@ -779,8 +794,11 @@ class NnueTrainer:
                     raise
                 import warnings
                 warnings.warn(f"collectives could not be captured into the step graph ({exc}); using the eager collective")
-                self.capture_collectives = False
+                captured = False
                 torch.cuda.synchronize(self.dev)
+            if self.dp.collectives and not self._ranks_agree(captured):  # all ranks or none
+                self._g_local.pop((slots, "many"), None)
+                self.capture_collectives = False
                 one_graph = False
         if not one_graph:
             if self.loss_ring.numel() < len(slots):
