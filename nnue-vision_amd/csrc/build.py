@@ -15,6 +15,10 @@ OUT = CSRC.parent / "nnue_hip" / "libnnue_hip.so"
 SOURCES = ["abi.cpp", "ft_kernels.hip", "ftb_kernels.hip", "ftm_kernels.hip", "feature_kernels.hip", "classifier_kernels.hip", "optim_kernels.hip", "input_kernels.hip", "engine_kernels.hip", "exchange_kernels.hip", "ftv_kernels.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result",
          "-fno-gpu-rdc", "-x", "hip", f"-I{ROOT / 'include'}", f"-I{CSRC}"]
+# NNUE_BUILD_ABLATIONS=1 also compiles the timing-only ablation variants tools/debug uses (NNUE_*_ABL* knobs: wrong results by
+# design, so a default build does not contain them)
+if os.environ.get("NNUE_BUILD_ABLATIONS") == "1":
+    FLAGS.append("-DNNUE_ABLATIONS")
 OBJ = CSRC / "build"  # per-source objects (git-ignored): only changed sources are recompiled, in parallel
 
 

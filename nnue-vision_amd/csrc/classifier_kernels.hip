@@ -1254,7 +1254,11 @@ int train_step_impl(const float* x, int pairwise, const float* w1, const float* 
         const int x_blocks = (int)((waves + 3) / 4);
         // timing-only ablation (tools/debug, WRONG small gradients): the d_x blocks alone -- what the launch would cost if the small
         // gradients rode elsewhere
+#ifdef NNUE_ABLATIONS  // compiled only with NNUE_BUILD_ABLATIONS=1 (csrc/build.py)
         static const int skip_small = [] { const char* e = getenv("NNUE_CLS_ABL_SKIP_SMALL"); return e ? atoi(e) : 0; }();
+#else
+        constexpr int skip_small = 0;
+#endif
         hipLaunchKernelGGL(l1_backward_x_small_wgrad, dim3((unsigned)(x_blocks + (skip_small ? 0 : wgrad_blocks))), dim3(256), 0, s, x, pairwise, w1,
                            (const float*)d_z1, B, L1, L2, d_x, x_blocks, sw);
       } else if (p.bwx_mfma) {

@@ -1826,10 +1826,12 @@ extern "C" int nnue_ftm_backward_values(const uint8_t* bits, const float* d_out,
     // 115 us with K tiles of 64 (72 KB, two per CU) and 147 us on the f32 MFMA at the 224x224 shape
     static const int kt = env_int("NNUE_FTM_BF6_KT", 32);  // developer knob
     const dim3 grid((unsigned)(s.tiles_m * s.tiles_n));
-    static const int abl = env_int("NNUE_FTM_BF6_ABL", 0);  // timing-only ablations (wrong results), tools/debug
+#ifdef NNUE_ABLATIONS  // timing-only ablations (WRONG results), tools/debug: compiled only with NNUE_BUILD_ABLATIONS=1 (csrc/build.py)
+    static const int abl = env_int("NNUE_FTM_BF6_ABL", 0);
 #define NNUE_ABL(N) if (abl == N) { hipLaunchKernelGGL((ftm_gemm_bf6_kernel<128, 64, ValEpi, 32, N>), grid, dim3(256), 0, st, ma, mb, epi, B, P, L1, s.tiles_n); return nnue_launch_status("nnue_ftm_backward_values"); }
     NNUE_ABL(1) NNUE_ABL(2) NNUE_ABL(3) NNUE_ABL(4) NNUE_ABL(5)
 #undef NNUE_ABL
+#endif
     static const int bn = env_int("NNUE_FTM_BF6_BN", 64);  // developer knob: 128-column tiles stage d_out half as often
     if (bn == 128) {
       const int tn = (P + 127) / 128;

@@ -148,13 +148,19 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 1) void ftv_values_kernel(const 
     w_off[j] = (unsigned)(row * K + 8 * q) * 4u;
   }
   u32x4 rw[kDepth][NB][2];
-  auto issue = [&](int t, auto slot_tag) {  // tile t into slot t % kDepth: DMA pieces first, table loads after them
+  // Tile t into slot t % kDepth: DMA pieces first, table loads after them.  Issued UNCONDITIONALLY, with t clamped to the last
+  // tile: past the end the queue is kept full with re-reads of the last tile into slots nobody reads any more, so that every
+  // step waits with the same counted s_waitcnt.  (A run-time choice between vmcnt(N) and vmcnt(0) made the compiler copy the asm
+  // loads' registers ahead of the wait on one of the two paths -- the destination of an asm load counts as written at the
+  // statement -- and the last K tile was intermittently read before it had landed: found by the knob matrix, audited in the ISA.)
+  auto issue = [&](int t_req, auto slot_tag) {
     constexpr int S = decltype(slot_tag)::value;
-    if (!(ABL == 1 && t >= kDepth)) {
+    const int t = t_req < tiles ? t_req : tiles - 1;
+    if (!(ABL == 1 && t_req >= kDepth)) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) dma16(src_piece[i] + (size_t)t * (3 * 32) * M, smem + S * kBuf + dst_piece[i]);
     }
-    if (!(ABL == 2 && t >= kDepth)) {
+    if (!(ABL == 2 && t_req >= kDepth)) {
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         load16<NT>(rw[S][j][0], weight, w_off[j] + (unsigned)t * (kKT * 4));
@@ -176,19 +182,18 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 1) void ftv_values_kernel(const 
   auto step = [&](int t, auto slot_tag) {
     constexpr int S = decltype(slot_tag)::value;
     // On entry tiles t and t + 1 are in flight (t + 2 is issued below, after the barrier has freed its slot): everything of
-    // tile t must have landed, tile t + 1's 6 + 2 NB operations may stay out.  The registers come back through the operands -- an
-    // asm load's destination counts as written at the statement, so without this hand-back the compiler may reuse it before
+    // tile t must have landed, tile t + 1's 6 + 2 NB operations may stay out.  The registers come back through the operands --
+    // an asm load's destination counts as written at the statement, so without this hand-back the compiler may reuse it before
     // the data lands (a too-large count here showed up as a memory fault: a late load landed in a register holding an address).
-    const bool last = ABL == 1 || ABL == 2 || t + 1 >= tiles;
     if constexpr (NB == 2) {
       u32x4 &w00 = rw[S][0][0], &w01 = rw[S][0][1], &w10 = rw[S][1][0], &w11 = rw[S][1][1];
-      if (last) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w00), "+v"(w01), "+v"(w10), "+v"(w11)::"memory");
+      if constexpr (ABL != 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w00), "+v"(w01), "+v"(w10), "+v"(w11)::"memory");
       else asm volatile("s_waitcnt vmcnt(10)" : "+v"(w00), "+v"(w01), "+v"(w10), "+v"(w11)::"memory");
     } else {
       static_assert(NB == 2 || NB == 4, "column blocks per wave");
       u32x4 &w00 = rw[S][0][0], &w01 = rw[S][0][1], &w10 = rw[S][1][0], &w11 = rw[S][1][1];
       u32x4 &w20 = rw[S][2][0], &w21 = rw[S][2][1], &w30 = rw[S][3][0], &w31 = rw[S][3][1];
-      if (last) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w00), "+v"(w01), "+v"(w10), "+v"(w11), "+v"(w20), "+v"(w21), "+v"(w30), "+v"(w31)::"memory");
+      if constexpr (ABL != 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w00), "+v"(w01), "+v"(w10), "+v"(w11), "+v"(w20), "+v"(w21), "+v"(w30), "+v"(w31)::"memory");
       else asm volatile("s_waitcnt vmcnt(14)" : "+v"(w00), "+v"(w01), "+v"(w10), "+v"(w11), "+v"(w20), "+v"(w21), "+v"(w30), "+v"(w31)::"memory");
     }
     static_assert(kDepth == 3, "the counted waits above are one tile's operations: 6 + 2 NB");
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 1) void ftv_values_kernel(const 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave's pieces of tile t are in LDS; every wave is done with tile t - 1 (slot (t - 1) % 3)
     asm volatile("" ::: "memory");
-    if (t + kDepth - 1 < tiles) issue(t + kDepth - 1, std::integral_constant<int, (S + kDepth - 1) % kDepth>{});
+    issue(t + kDepth - 1, std::integral_constant<int, (S + kDepth - 1) % kDepth>{});  // (clamped past the end: see issue)
     const unsigned char* __restrict__ buf = smem + S * kBuf;
     // fragments of row block i + 1 are requested before row block i's MFMAs (two register sets, ping-pong; the scheduling
     // barrier keeps the compiler from sinking the reads to their use, where every block would expose the LDS latency)
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 1) void ftv_values_kernel(const 
   using S1 = std::integral_constant<int, 1>;
   using S2 = std::integral_constant<int, 2>;
   issue(0, S0{});
-  if (tiles > 1) issue(1, S1{});
+  issue(1, S1{});
   int t = 0;
   for (; t + 3 <= tiles; t += 3) {
     step(t, S0{});
@@ -236,6 +241,11 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 1) void ftv_values_kernel(const 
   }
   if (t < tiles) step(t++, S0{});
   if (t < tiles) step(t++, S1{});
+  // retire the two filler tiles still in flight before any of their registers or LDS slots can be reused
+#pragma unroll
+  for (int sl = 0; sl < kDepth; ++sl)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rw[sl][j][0]), "+v"(rw[sl][j][1])::"memory");
   // ---- epilogue: acc[i][j][e] = C[m_base + 16 i + 4 q + e][n_wave + 16 j + r], kept where the position is active
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -291,7 +301,9 @@ int ftv_launch(const uint8_t* bits, const float* d_out, const float* weight, int
   const int nb = ftv_nb(), bn = 64 * nb;
   const dim3 grid((unsigned)((P + bn - 1) / bn), (unsigned)((B + kBM - 1) / kBM));
   const bool nt = (size_t)F * L1 * 4 > (64u << 20);  // a table larger than the caches is streamed once: non-temporal loads
-  static const int abl = [] { const char* e = getenv("NNUE_FTM_VAL_ABL"); return e ? atoi(e) : 0; }();  // timing-only ablations
+#ifdef NNUE_ABLATIONS  // timing-only ablations (WRONG results), tools/debug: compiled only with NNUE_BUILD_ABLATIONS=1 (csrc/build.py)
+  static const int abl = [] { const char* e = getenv("NNUE_FTM_VAL_ABL"); return e ? atoi(e) : 0; }();
+#endif
   static const int prio = [] { const char* e = getenv("NNUE_FTM_VAL_PRIO"); return e ? atoi(e) : 0; }();  // developer knob: see the kernel
 #define NNUE_FTV(A, NBV)                                                                                                                      \
   do {                                                                                                                                        \
@@ -299,8 +311,10 @@ int ftv_launch(const uint8_t* bits, const float* d_out, const float* weight, int
     else hipLaunchKernelGGL((ftv_values_kernel<A, false, NBV>), grid, dim3(256), 0, st, planes, weight, bits, d_conv_out, B, P, L1, F, prio);   \
   } while (0)
   if (nb == 4) NNUE_FTV(0, 4);
+#ifdef NNUE_ABLATIONS
   else if (abl == 1) NNUE_FTV(1, 2);
   else if (abl == 2) NNUE_FTV(2, 2);
+#endif
   else NNUE_FTV(0, 2);
 #undef NNUE_FTV
   return NNUE_OK;

@@ -87,6 +87,8 @@ def test_value_gradient_by_lds_dma_against_float64(hip, shape, monkeypatch):
     equality with the default six-plane tile kernel's term order is NOT expected -- both are held to the float64 value."""
     b, fps, gh, gw, f, l1 = shape
     monkeypatch.setenv("NNUE_FTM_VAL_DMA", "1")
+    if int(hip.load().nnue_ftm_backward_values_scratch(b, f, fps * gh * gw, l1)) == 0:
+        pytest.skip("the six-plane products are switched off (NNUE_FTM_BF16 / NNUE_FTM_VAL_BF6): this shape takes the f32 kernels")
     assert int(hip.load().nnue_ftm_backward_values_scratch(b, f, fps * gh * gw, l1)) == 3 * b * l1 * 2
     gen = torch.Generator().manual_seed(b + f)
     conv_out = torch.randn(b, fps, gh, gw, generator=gen)
@@ -100,9 +102,11 @@ def test_value_gradient_by_lds_dma_against_float64(hip, shape, monkeypatch):
     assert_close_grad(d_val.view(conv_out.shape), ref_dval, "d_conv_out (LDS-DMA kernel)", rtol=2e-5)
     active = (conv_out > 0.17).reshape(b, -1)
     assert not bool(d_val.view(b, -1)[~active.to(DEV)].any())
-    assert torch.equal(hip.ftm_backward_values(g(d_out), g(weight), fm), d_val)  # fixed order: reproducible
+    for _ in range(8):  # fixed order: reproducible (and a guard against the intermittent early read this kernel once had)
+        assert torch.equal(hip.ftm_backward_values(g(d_out), g(weight), fm), d_val)
     # the default: the six-plane tile kernel, d_out split in every workgroup, no workspace
     monkeypatch.setenv("NNUE_FTM_VAL_DMA", "0")
+    monkeypatch.setenv("NNUE_FTM_VAL_PLANES", "0")
     assert int(hip.load().nnue_ftm_backward_values_scratch(b, f, fps * gh * gw, l1)) == 0
     d_tile = hip.ftm_backward_values(g(d_out), g(weight), fm)
     assert_close_grad(d_tile.view(conv_out.shape), ref_dval, "d_conv_out (tile kernel)", rtol=2e-5)

@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of the 224x224 step under rocprofv3 --kernel-trace --stats: each argument is "name ENV=VALUE ..." ("name" alone = defaults).
+# (The NNUE_*_ABL* knobs exist only in a library built with NNUE_BUILD_ABLATIONS=1 python nnue-vision_amd/csrc/build.py --force.)
 # Usage (via gpurun): bash tools/debug/c4_ab.sh OUTDIR [workload] -- "new" "old NNUE_FTM_VAL_DMA=0"
 O=$PWD/$1; W=${2:-c4}; shift 2; [ "$1" = "--" ] && shift
 R=$PWD; mkdir -p $O; cd /tmp; export TMPDIR=/tmp

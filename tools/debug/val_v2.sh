@@ -1,5 +1,6 @@
 #!/bin/bash
 # Value gradient at the 224x224 shape: the LDS-DMA kernel (ftv_kernels.hip) vs the six-plane tile kernel, + timing-only ablations.
+# (The NNUE_*_ABL* knobs exist only in a library built with NNUE_BUILD_ABLATIONS=1 python nnue-vision_amd/csrc/build.py --force.)
 # Usage (via gpurun): bash tools/debug/val_v2.sh OUTDIR
 O=$PWD/$1; R=$PWD; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 run() { # name, env...
