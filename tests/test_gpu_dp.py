@@ -145,6 +145,16 @@ def test_two_ranks_exchanging_the_gradient_factors(tmp_path, use_graph):
     _run(tmp_path, 2, "gloo", use_graph, {"NNUE_DP_FACTOR_EXCHANGE": "1"})
 
 
+@pytest.mark.parametrize("env", ({"NNUE_DP_FACTOR_EXCHANGE": "1"}, {"NNUE_DP_SHARDED_UPDATE": "1"}, {}))
+def test_four_ranks_on_one_gpu(tmp_path, env):
+    """world = 4 (four processes sharing the GPU, gloo): four gathered chunks / shards instead of two -- the factor exchange's
+    global batch of 4 x 8 rows, the sharded update's quarter shards, the plain all-reduce -- bitwise identical replicas, the
+    single-process trajectory, and a short last batch that leaves the last rank empty (25 real samples of 32: 8 + 8 + 8 + 1... the
+    fourth rank holds one)."""
+    _run(tmp_path, 4, "gloo", True, env)
+    _run(tmp_path, 4, "gloo", True, env, short_last=True)
+
+
 def test_two_ranks_exchanging_factors_with_a_short_last_batch(tmp_path):
     _run(tmp_path, 2, "gloo", True, {"NNUE_DP_FACTOR_EXCHANGE": "1"}, short_last=True)
 
