@@ -930,6 +930,8 @@ ClsPlan make_plan(int B, int L1, int L2, int pairwise, int K = 1) {
     int ks = 1;
     while (tiles * ks < 1024 && L1 % (ks * 2 * 16) == 0 && L1 / (ks * 2) >= 64) ks *= 2;
     if (pairwise && ks == 1) ks = 2;
+    static const int force_ks = [] { const char* e = getenv("NNUE_CLS_FWD_KSPLIT"); return e ? atoi(e) : 0; }();  // developer knob
+    if (force_ks >= 2 && (force_ks & (force_ks - 1)) == 0 && L1 % (force_ks * 16) == 0 && L1 / force_ks >= 32) ks = force_ks;
     p.fwd_ksplit = ks;
   }
   p.bww_mfma = (L1 % 64 == 0) && (L2 % 32 == 0);
