@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 28
+#define NNUE_HIP_ABI_VERSION 29
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -49,6 +49,9 @@ extern "C" {
 #define NNUE_E_SCRATCH (-4) /* scratch buffer too small */
 
 typedef void* nnue_stream_t; /* hipStream_t */
+/* arguments of the classifier's small-gradient tile family when it rides in nnue_ftm_backward's launch (opaque; filled by
+ * nnue_classifier_train_rider, read by nnue_ftm_backward[_bucketed]) */
+typedef struct nnue_cls_rider { unsigned char opaque[256]; } nnue_cls_rider;
 
 int nnue_hip_abi_version(void);
 const char* nnue_hip_last_error(void);
@@ -263,11 +266,15 @@ int64_t nnue_ftm_backward_sq_count(int B, int F, int P, int L1); /* floats nnue_
  * sq_partial (may be NULL): nnue_ftm_backward_sq_count(B, F, P, L1) floats (declared above) that receive, per
  * weight-gradient tile, the sum of the squares of the elements it wrote -- together the squared norm of
  * d_weight[0 .. min(F-1, P)) -- so that nnue_sgd_step (ext_partial) need not read those rows again for
- * clip_grad_norm_ (train.py:363-364). */
+ * clip_grad_norm_ (train.py:363-364).
+ * small != NULL (filled by nnue_classifier_train_rider; merged-launch shapes only): the classifier's small batch-reduced
+ * gradients (d_w3, d_w2, the three bias gradients; autograd of nnue.py:728-734) and the mean loss (train.py:250-254) run as
+ * one more tile family of this launch -- ~30 workgroups beside a few hundred -- instead of beside the classifier's d_x tiles
+ * (nnue_classifier_train_step phases bit 32). */
 int nnue_ftm_backward(const uint8_t* bits, const float* sink, const float* d_out, const float* weight,
                       int B, int F, int P, int L1, float* d_weight, float* d_bias, float* d_conv_out,
                       const float* ft, const float* d_z1, int L2, float* d_w1, float* sq_partial,
-                      nnue_stream_t stream);
+                      const nnue_cls_rider* small, nnue_stream_t stream);
 
 /* ---- pairwise product + SimpleClassifier -------------------------------------- */
 
@@ -308,7 +315,9 @@ int nnue_classifier_backward(const float* x, int pairwise,
  * Adding 16 (not together with 4) says d_w1 is produced by nnue_ftm_backward's rider from the d_z1 this call leaves
  * in scratch at byte offset nnue_classifier_train_dz1_offset (-1 for non-positive sizes): no first-layer weight
  * product and no slab sum are launched here, d_w1 is not written; with both phases in the one call (19, 27) the
- * small weight/bias gradients and the mean loss share the d_x launch.
+ * small weight/bias gradients and the mean loss share the d_x launch -- unless 32 is added as well (51, 59): then they
+ * are left to nnue_ftm_backward's launch too (its `small` argument, filled by nnue_classifier_train_rider with the same
+ * tensors and scratch), and the d_x launch holds only d_x tiles.
  * scratch >= nnue_classifier_train_scratch(B, L1, L2, L3, C) bytes. */
 int64_t nnue_classifier_train_scratch(int B, int L1, int L2, int L3, int C);
 int64_t nnue_classifier_train_dz1_offset(int B, int L1, int L2, int L3, int C, int pairwise);
@@ -321,6 +330,14 @@ int nnue_classifier_train_step(const float* x, int pairwise,
                                float* d_x, float* d_w1, float* d_b1, float* d_w2, float* d_b2,
                                float* d_w3, float* d_b3,
                                void* scratch, int64_t scratch_bytes, int phases, nnue_stream_t stream);
+/* A host-side call (no launch) that fills `out` with the arguments of the small-gradient tile family for a step run with
+ * phases bit 32 -- d_w3, d_w2, d_b3, d_b2, d_b1 (autograd of nnue.py:728-734) and the mean loss (train.py:250-254) then run
+ * inside nnue_ftm_backward's launch (its `small` argument).  Same tensors and scratch as the train step; buckets = NULL
+ * for one layer stack. */
+int nnue_classifier_train_rider(int pairwise, int B, int L1, int L2, int L3, int C, const float* h1, const float* h2,
+                                const float* sample_loss, float* loss, float* d_b1, float* d_w2, float* d_b2,
+                                float* d_w3, float* d_b3, void* scratch, int64_t scratch_bytes,
+                                const struct nnue_buckets* buckets, nnue_cls_rider* out);
 
 /* ---- bucketed layer stacks (build extension; BASELINE configs[2]) -------------------------------------------------
  *
@@ -442,7 +459,7 @@ int nnue_ftm_backward_bucketed(const uint8_t* bits, const float* sink, const flo
                                int B, int F, int P, int L1, float* d_weight, float* d_bias, float* d_conv_out,
                                const float* ft_grouped, const float* d_z1_grouped, int L2, float* d_w1,
                                float* sq_partial, int K, const int32_t* seg, int grouped_rows,
-                               nnue_stream_t stream);
+                               const nnue_cls_rider* small, nnue_stream_t stream);
 
 /* ---- loss + step tail ---------------------------------------------------------- */
 

@@ -10,36 +10,14 @@
 // tail kernel working out of LDS.  Split-K partials are summed in fixed order: reproducible.
 #include <type_traits>
 #include <cstdlib>
+#include <cstring>
 
 #include "common.h"
+#include "small_wgrad.h"
 
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-// Bucketed layer stacks (build extension, SURVEY section 7 / BASELINE configs[2]: K independent SimpleClassifier weight
-// sets [K][out][in], one selected per sample by its active-feature count -- the vision analogue of the piece-count
-// buckets the engine's LayerStack vector descends from, engine/src/nnue_engine.cpp:619-635).  K == 1 with null pointers
-// is the reference's single stack and takes exactly the code it always took.  nnue_bucket_group sorts the samples by
-// bucket into 16-row tiles, so that every MFMA tile multiplies by ONE bucket's weights ("batched per-bucket MFMA"):
-//   bucket[b]         bucket of sample b
-//   rows[16 t + i]    sample in row i of tile t, ascending inside a bucket; -1 = padding
-//   tile_bucket[t]    bucket of tile t; -1 = unused tile
-//   seg[k], seg[k+1]  row range (multiples of 16) of bucket k
-struct Buckets {
-  int K;
-  const int* bucket;
-  const int* rows;
-  const int* tile_bucket;
-  const int* seg;
-  int tiles;
-};
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
-  return v;
-}
 
 __device__ __forceinline__ float act_fn(float z, float clip) {
   const float r = fmaxf(z, 0.0f);
@@ -509,173 +487,10 @@ __global__ __launch_bounds__(128) void tail_backward_kernel(const float* __restr
   }
 }
 
-// Small batch reductions, one workgroup per 16 x 16 output tile (f32 MFMA, K = the batch):
-//   d_w3 [C, L3] = d_logits^T h2 | d_w2 [L3, L2] = d_z2^T h1 | d_b3 [C] | d_b2 [L3] | d_b1 [L2] = column sums
-// (The earlier form -- one wave per four outputs, lanes striding over the batch -- touched one cache line per lane and
-// load: 9.1 us at the CIFAR batch-512 shape, the longest part of the d_x launch it rides in.)
-struct SmallWgrad {
-  const float *d_logits, *d_z2, *d_z1, *h1, *h2;
-  int B, L2, L3, C;
-  float *d_w3, *d_b3, *d_w2, *d_b2, *d_b1;
-  const float* sample_loss;
-  float* loss_out;
-  int wgrad_blocks;
-  const float* slabs;
-  int n_slabs;
-  long long slab_count;
-  float* d_w1;
-  Buckets bk;    // bk.rows != NULL: every output exists once per bucket and sums over that bucket's samples
-  int bww_klen;  // rows per d_w1 slab slice (bucketed slab sum: slice s of bucket k is empty from s*klen >= its rows)
-};
-
-__device__ __forceinline__ void small_wgrad_body(const SmallWgrad& a, int blk) {
-  const float* __restrict__ d_logits = a.d_logits;
-  const float* __restrict__ d_z2 = a.d_z2;
-  const float* __restrict__ d_z1 = a.d_z1;
-  const float* __restrict__ h1 = a.h1;
-  const float* __restrict__ h2 = a.h2;
-  const float* __restrict__ sample_loss = a.sample_loss;
-  const float* __restrict__ slabs = a.slabs;
-  float* __restrict__ d_w3 = a.d_w3; float* __restrict__ d_b3 = a.d_b3; float* __restrict__ d_w2 = a.d_w2;
-  float* __restrict__ d_b2 = a.d_b2; float* __restrict__ d_b1 = a.d_b1; float* __restrict__ loss_out = a.loss_out;
-  float* __restrict__ d_w1 = a.d_w1;
-  const int B = a.B, L2 = a.L2, L3 = a.L3, C = a.C, wgrad_blocks = a.wgrad_blocks, n_slabs = a.n_slabs;
-  const long long slab_count = a.slab_count;
-  const Buckets& bk = a.bk;
-  if (blk >= wgrad_blocks) {  // piggy-backed pass: fixed-order sum of the d_w1 split-K slabs
-    const long long i = ((long long)(blk - wgrad_blocks) * 256 + threadIdx.x) * 4;
-    if (i >= slab_count) return;
-    int nz = n_slabs;
-    if (bk.rows) {  // slices of this element's bucket that hold rows (the others were never written)
-      const int kb = (int)(i / (slab_count / bk.K));
-      const int len = bk.seg[kb + 1] - bk.seg[kb];
-      nz = (len + a.bww_klen - 1) / a.bww_klen;
-      nz = nz < n_slabs ? nz : n_slabs;
-    }
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (nz > 0) acc = *reinterpret_cast<const float4*>(slabs + i);
-    for (int s2 = 1; s2 < nz; ++s2) {
-      const float4 v = *reinterpret_cast<const float4*>(slabs + (size_t)s2 * slab_count + i);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    *reinterpret_cast<float4*>(d_w1 + i) = acc;
-    return;
-  }
-  // One workgroup per 16 x 16 output tile of out[m][n] = sum_b A[b][m] * Bm[b][n] on the f32 MFMA: the batch is walked in
-  // chunks of 16 rows, chunk c by wave c % 4 (64-byte runs of each operand row per load instead of one line per lane), the
-  // four waves' accumulators are added in wave order through LDS.  Bias gradients are the same tile with A == 1 (row 0 is
-  // the column sum).  With layer stacks there is one workgroup per (tile, stack), contracting that stack's grouped rows
-  // (zeros for a stack without samples).
-  __shared__ float red[4][256];
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int r = lane & 15, q = lane >> 4;
-  const int t3n = (L3 + 15) / 16, t2n = (L2 + 15) / 16, tcm = (C + 15) / 16;
-  const int n_w3 = tcm * t3n, n_w2 = t3n * t2n;
-  const int stacks = bk.rows ? bk.K : 1;
-  const int kb = blk % stacks;  // a workgroup forms its tile for ONE layer stack
-  int t = blk / stacks;
-  const float* A;
-  const float* Bm;
-  float* dst;
-  int lda = 0, ldb, ldd = 0, M, N, m0 = 0, n0;
-  size_t stride_k;
-  if (t < n_w3) {
-    A = d_logits; lda = C; Bm = h2; ldb = L3; dst = d_w3; ldd = L3; M = C; N = L3; m0 = (t / t3n) * 16; n0 = (t % t3n) * 16; stride_k = (size_t)C * L3;
-  } else if ((t -= n_w3) < n_w2) {
-    A = d_z2; lda = L3; Bm = h1; ldb = L2; dst = d_w2; ldd = L2; M = L3; N = L2; m0 = (t / t2n) * 16; n0 = (t % t2n) * 16; stride_k = (size_t)L3 * L2;
-  } else if ((t -= n_w2) < tcm) {
-    A = nullptr; Bm = d_logits; ldb = C; dst = d_b3; M = 1; N = C; n0 = t * 16; stride_k = C;
-  } else if ((t -= tcm) < t3n) {
-    A = nullptr; Bm = d_z2; ldb = L3; dst = d_b2; M = 1; N = L3; n0 = t * 16; stride_k = L3;
-  } else if ((t -= t3n) < t2n) {
-    A = nullptr; Bm = d_z1; ldb = L2; dst = d_b1; M = 1; N = L2; n0 = t * 16; stride_k = L2;
-  } else {
-    if (t == t2n && kb == 0 && loss_out != nullptr && wave == 0) {  // one more workgroup: mean of the per-sample losses, fixed order
-      float acc = 0.f;
-      for (int b = lane; b < B; b += 64) acc += sample_loss[b];
-      acc = wave_sum(acc);
-      if (lane == 0) *loss_out = acc / (float)B;
-    }
-    return;
-  }
-  const bool m_ok = m0 + r < M, n_ok = n0 + r < N;
-  const int mc = m_ok ? m0 + r : 0, nc = n_ok ? n0 + r : 0;  // clamped: every load below is unconditional and in range
-  dst += (size_t)kb * stride_k;
-  {
-    const int g_lo = bk.rows ? bk.seg[kb] : 0, g_hi = bk.rows ? bk.seg[kb + 1] : B;
-    const int nch = (g_hi - g_lo + 15) / 16;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    constexpr int U = 4;  // chunks of loads in flight per wave
-    // straight-line load batches (no branch around a load: a conditional load drags an s_waitcnt vmcnt(0) behind it):
-    // rows beyond the segment / padding rows read row 0 and are multiplied out
-    auto chunk_batch = [&](int c0, auto rows_tag, auto ones_tag) {
-      constexpr bool ROWS = decltype(rows_tag)::value, ONES = decltype(ones_tag)::value;
-      int bi[U][4];
-      bool ok[U][4];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int g = g_lo + 16 * (c0 + 4 * u) + 4 * q;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          ok[u][e] = g + e < g_hi;
-          const int gi = ok[u][e] ? g + e : g_lo;
-          bi[u][e] = ROWS ? bk.rows[gi] : gi;
-        }
-      }
-      float av[U][4], bv[U][4];
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (ROWS) ok[u][e] = ok[u][e] && bi[u][e] >= 0;
-          const int b = ok[u][e] ? bi[u][e] : 0;
-          av[u][e] = ONES ? 1.0f : A[(size_t)b * lda + mc];
-          bv[u][e] = Bm[(size_t)b * ldb + nc];
-        }
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float a_ = (ONES || (ok[u][e] && m_ok)) ? av[u][e] : 0.0f;
-          const float b_ = (ok[u][e] && n_ok) ? bv[u][e] : 0.0f;
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b_, acc, 0, 0, 0);
-        }
-    };
-    using T = std::true_type;
-    using F = std::false_type;
-    if (bk.rows) {
-      if (A) for (int c0 = wave; c0 < nch; c0 += 4 * U) chunk_batch(c0, T{}, F{});
-      else for (int c0 = wave; c0 < nch; c0 += 4 * U) chunk_batch(c0, T{}, T{});
-    } else {
-      if (A) for (int c0 = wave; c0 < nch; c0 += 4 * U) chunk_batch(c0, F{}, F{});
-      else for (int c0 = wave; c0 < nch; c0 += 4 * U) chunk_batch(c0, F{}, T{});
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) red[wave][lane * 4 + e] = acc[e];
-    __syncthreads();
-    if (wave == 0 && n_ok) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int i = lane * 4 + e, m = m0 + 4 * q + e;
-        const float v = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
-        if (A) {
-          if (m < M) dst[(size_t)m * ldd + n0 + r] = v;
-        } else if (4 * q + e == 0) {
-          dst[n0 + r] = v;
-        }
-      }
-    }
-    __syncthreads();
-  }
+__global__ __launch_bounds__(256) void small_wgrad_kernel(SmallWgrad a) {
+  __shared__ float red[1024];
+  small_wgrad_body(a, (int)blockIdx.x, red);
 }
-
-// number of output tiles of small_wgrad_body's five families; the launch takes tiles * K workgroups (+ 1 for the mean loss)
-inline int small_wgrad_tiles(int L2, int L3, int C) {
-  const int t3 = (L3 + 15) / 16, t2 = (L2 + 15) / 16, tc = (C + 15) / 16;
-  return tc * t3 + t3 * t2 + tc + t3 + t2;
-}
-
-__global__ __launch_bounds__(256) void small_wgrad_kernel(SmallWgrad a) { small_wgrad_body(a, (int)blockIdx.x); }
 
 // ------------------------------------------------------------------ fused narrow layers + loss (training)
 // Per sample, out of LDS: h1 = act(sum of split-K slabs + b1), h2, logits, softmax cross-entropy, d_logits,
@@ -1146,7 +961,10 @@ __global__ __launch_bounds__(256) void l1_backward_x_small_wgrad(const float* __
                                                                  const float* __restrict__ d_z1, int B, int L1, int L2,
                                                                  float* __restrict__ d_x, int x_blocks, SmallWgrad a) {
   if ((int)blockIdx.x < x_blocks) l1_backward_x_body(x, pairwise, w1, d_z1, B, L1, L2, d_x, blockIdx.x, a.bk);
-  else small_wgrad_body(a, (int)blockIdx.x - x_blocks);
+  else {
+    __shared__ float red[1024];
+    small_wgrad_body(a, (int)blockIdx.x - x_blocks, red);
+  }
 }
 
 // ---------------------------------------------------------------- fused training step of the classifier block
@@ -1181,10 +999,12 @@ int train_step_impl(const float* x, int pairwise, const float* w1, const float* 
                     nnue_stream_t stream) {
   NNUE_REQUIRE(x && w1 && b1 && w2 && b2 && w3 && b3 && labels && h1 && h2 && logits && sample_loss && loss && scratch,
                NNUE_E_ARG, "nnue_classifier_train_step: null pointer");
-  NNUE_REQUIRE(phases >= 1 && phases <= 31 && (phases & 3) && (phases & 20) != 20, NNUE_E_ARG,
+  NNUE_REQUIRE(phases >= 1 && phases <= 63 && (phases & 3) && (phases & 20) != 20 && (!(phases & 32) || (phases & 19) == 19), NNUE_E_ARG,
                "nnue_classifier_train_step: phases = 1 (activations + d_x) | 2 (weight gradients + loss) [| 4: first-layer weight product beside "
-               "d_x] [| 8: layer-1 slabs already at the start of scratch] [| 16 (not with 4): d_w1 comes from nnue_ftm_backward]");
+               "d_x] [| 8: layer-1 slabs already at the start of scratch] [| 16 (not with 4): d_w1 comes from nnue_ftm_backward] [| 32 (with 1, 2 "
+               "and 16): the small gradients and the mean loss ride in nnue_ftm_backward's launch as well]");
   const bool ext_dw1 = (phases & 16) != 0;
+  const bool ext_small = (phases & 32) != 0;
   const bool ext_slabs = (phases & 8) != 0;
   const int K = bk.K;
   NNUE_REQUIRE(K == 1 || !ext_slabs, NNUE_E_ARG,
@@ -1228,6 +1048,8 @@ int train_step_impl(const float* x, int pairwise, const float* w1, const float* 
                       slabs, slab_pass && !ext_dw1 ? p.bww_ksplit : 0, count, d_w1, bk, p.bww_klen};
   // both phases in one call with d_w1 left to nnue_ftm_backward: the small gradients ride in the d_x launch
   const bool wgrad_rides = (phases & 3) == 3 && ext_dw1 && p.bwx_mfma && d_x != nullptr;
+  NNUE_REQUIRE(!ext_small || wgrad_rides, NNUE_E_SHAPE,
+               "nnue_classifier_train_step: phases bit 32 needs the d_x launch the small gradients otherwise ride in (MFMA shapes, d_x requested)");
   if (phases & 1) {
     if (ext_slabs) {
       // part[L1/64][B][L2] was written by nnue_ftm_forward_l1 (the FeatureTransformer forward's epilogue)
@@ -1261,7 +1083,7 @@ int train_step_impl(const float* x, int pairwise, const float* w1, const float* 
 #else
         constexpr int skip_small = 0;
 #endif
-        hipLaunchKernelGGL(l1_backward_x_small_wgrad, dim3((unsigned)(x_blocks + (skip_small ? 0 : wgrad_blocks))), dim3(256), 0, s, x, pairwise, w1,
+        hipLaunchKernelGGL(l1_backward_x_small_wgrad, dim3((unsigned)(x_blocks + ((skip_small || ext_small) ? 0 : wgrad_blocks))), dim3(256), 0, s, x, pairwise, w1,
                            (const float*)d_z1, B, L1, L2, d_x, x_blocks, sw);
       } else if (p.bwx_mfma) {
         const long long waves = (long long)m_tiles * (L1 / 32);
@@ -1313,6 +1135,32 @@ extern "C" int64_t nnue_classifier_train_dz1_grouped_offset(int B, int L1, int L
 extern "C" int64_t nnue_classifier_train_x_grouped_offset(int B, int L1, int L2, int L3, int C, int K) {
   if (B <= 0 || L1 <= 0 || L2 <= 0 || L3 <= 0 || C <= 0 || K <= 1 || K > kMaxBuckets) return -1;
   return train_layout(make_plan(B, L1, L2, 1, K), B, L1, L2, L3, C, K).x_g * (int64_t)sizeof(float);
+}
+
+// The arguments of the small-gradient tile family for a step run with phases bit 32 (host side only; what train_step_impl builds
+// for its own launch, with no slab pass: d_w1 belongs to nnue_ftm_backward's rider in this mode)
+extern "C" int nnue_classifier_train_rider(int pairwise, int B, int L1, int L2, int L3, int C, const float* h1, const float* h2,
+                                           const float* sample_loss, float* loss, float* d_b1, float* d_w2, float* d_b2, float* d_w3,
+                                           float* d_b3, void* scratch, int64_t scratch_bytes, const nnue_buckets* buckets,
+                                           nnue_cls_rider* out) {
+  NNUE_REQUIRE(h1 && h2 && sample_loss && loss && d_b1 && d_w2 && d_b2 && d_w3 && d_b3 && scratch && out, NNUE_E_ARG,
+               "nnue_classifier_train_rider: null pointer");
+  NNUE_REQUIRE(B > 0 && L1 > 0 && L2 > 0 && L3 > 0 && C > 0, NNUE_E_ARG, "nnue_classifier_train_rider: sizes must be positive");
+  Buckets bk;
+  const int rc = buckets_from(buckets, B, &bk, "nnue_classifier_train_rider");
+  if (rc != NNUE_OK) return rc;
+  const ClsPlan p = make_plan(B, L1, L2, pairwise, bk.K);
+  const TrainLayout t = train_layout(p, B, L1, L2, L3, C, bk.K);
+  NNUE_REQUIRE(scratch_bytes >= t.total * (int64_t)sizeof(float), NNUE_E_SCRATCH, "nnue_classifier_train_rider: scratch %lld < %lld bytes",
+               (long long)scratch_bytes, (long long)(t.total * 4));
+  float* base = static_cast<float*>(scratch);
+  const int wgrad_blocks = small_wgrad_tiles(L2, L3, C) * bk.K + 1;
+  const SmallWgrad sw{base + t.d_logits, base + t.d_z2, base + t.d_z1, h1, h2, B, L2, L3, C, d_w3, d_b3, d_w2, d_b2, d_b1, sample_loss, loss,
+                      wgrad_blocks, nullptr, 0, (long long)bk.K * L2 * L1, nullptr, bk, p.bww_klen};
+  static_assert(sizeof(SmallWgrad) <= sizeof(nnue_cls_rider), "nnue_cls_rider is too small");
+  memset(out, 0, sizeof(*out));
+  memcpy(out, &sw, sizeof(sw));
+  return NNUE_OK;
 }
 
 extern "C" int nnue_classifier_train_step(const float* x, int pairwise, const float* w1, const float* b1, const float* w2,

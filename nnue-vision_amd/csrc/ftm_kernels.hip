@@ -23,8 +23,10 @@
 // issued right after the barrier that publishes the current one and stay in flight during its MFMAs.
 #include "common.h"
 #include "ftv_kernels.h"
+#include "small_wgrad.h"
 
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 namespace {
@@ -1302,7 +1304,7 @@ struct CwArgs {  // classifier first-layer weight gradient riding in the same la
 template <int WM, int WN, int WK, int VM, int VN, int VK>
 __global__ __launch_bounds__(256) void ftm_backward_kernel(Mat wa, Mat wb, BwwEpi we, int wM, int wN, int wK, int w_tiles_n, int n_w,
                                                            Mat va, Mat vb, ValEpi ve, int vM, int vN, int vK, int v_tiles_n, int n_v,
-                                                           CwArgs c, TailRows t) {
+                                                           CwArgs c, TailRows t, SmallWgrad sw) {
   constexpr int kW = gemm_lds_floats<WM, WN, WK, false, false>(), kV = gemm_lds_floats<VM, VN, VK, true, true>();
   constexpr int kC = gemm_lds_floats<WM, WN, WK, false, false>();  // the rider's tiles have the weight tiles' shape
   constexpr int kWV = kW > kV ? kW : kV;
@@ -1327,8 +1329,9 @@ __global__ __launch_bounds__(256) void ftm_backward_kernel(Mat wa, Mat wb, BwwEp
       gemm_tile<WM, WN, WK, false, false, CwEpi>(smem, c.a, c.b, c.e, c.M, c.N, 0, c.K, c.tiles_n, t, 0);
     }
   } else {
-    const int i = blk - n_w - n_v - c.n_c;
-    tail_rows_block(t, i % t.col_blocks, i / t.col_blocks, smem);
+    const int i = blk - n_w - n_v - c.n_c, n_t = t.col_blocks * (1 + t.zero_slices);
+    if (i < n_t) tail_rows_block(t, i % t.col_blocks, i / t.col_blocks, smem);
+    else small_wgrad_body(sw, i - n_t, smem);  // the classifier's small gradients + mean loss (blocks exist only when they ride here)
   }
 }
 
@@ -1337,7 +1340,7 @@ __global__ __launch_bounds__(256) void ftm_backward_kernel(Mat wa, Mat wb, BwwEp
 template <int WM, int VM, int VN, int VK, bool V6 = false, bool W64 = false>
 __global__ __launch_bounds__(256) void ftm_backward_bf_kernel(Mat wa, Mat wb, BwwEpi we, int wM, int wN, int wK, int w_tiles_n, int n_w,
                                                               Mat va, Mat vb, ValEpi ve, int vM, int vN, int vK, int v_tiles_n, int n_v,
-                                                              CwArgs c, TailRows t) {
+                                                              CwArgs c, TailRows t, SmallWgrad sw) {
   constexpr int kW = W64 ? gemm_bf64_lds_bytes<WM>() : gemm_bf_lds_bytes<WM, 64>(), kV = V6 ? gemm_bf6_lds_bytes<VM, VN>() : gemm_lds_floats<VM, VN, VK, true, true>() * 4;
   constexpr int kC = gemm_lds_floats<32, 64, 128, false, false>() * 4;
   constexpr int kWV = kW > kV ? kW : kV;
@@ -1365,8 +1368,9 @@ __global__ __launch_bounds__(256) void ftm_backward_bf_kernel(Mat wa, Mat wb, Bw
       gemm_tile<32, 64, 128, false, false, CwEpi>(smem, c.a, c.b, c.e, c.M, c.N, 0, c.K, c.tiles_n, t2, 0);
     }
   } else {
-    const int i = blk - n_w - n_v - c.n_c;
-    tail_rows_block(t, i % t.col_blocks, i / t.col_blocks, smem);
+    const int i = blk - n_w - n_v - c.n_c, n_t = t.col_blocks * (1 + t.zero_slices);
+    if (i < n_t) tail_rows_block(t, i % t.col_blocks, i / t.col_blocks, smem);
+    else small_wgrad_body(sw, i - n_t, smem);  // the classifier's small gradients + mean loss (blocks exist only when they ride here)
   }
 }
 
@@ -1948,28 +1952,28 @@ extern "C" int nnue_ftm_backward_cw_supported(int B, int F, int P, int L1, int L
 namespace {
 int ftm_backward_impl(const uint8_t* bits, const float* sink, const float* d_out, const float* weight, int B, int F, int P, int L1,
                       float* d_weight, float* d_bias, float* d_conv_out, const float* ft, const float* d_z1, int L2, float* d_w1,
-                      float* sq_partial, int K, const int32_t* seg, int grouped_rows, nnue_stream_t stream);
+                      float* sq_partial, int K, const int32_t* seg, int grouped_rows, const nnue_cls_rider* small, nnue_stream_t stream);
 }
 extern "C" int nnue_ftm_backward(const uint8_t* bits, const float* sink, const float* d_out, const float* weight, int B, int F, int P,
                                  int L1, float* d_weight, float* d_bias, float* d_conv_out, const float* ft, const float* d_z1, int L2,
-                                 float* d_w1, float* sq_partial, nnue_stream_t stream) {
+                                 float* d_w1, float* sq_partial, const nnue_cls_rider* small, nnue_stream_t stream) {
   return ftm_backward_impl(bits, sink, d_out, weight, B, F, P, L1, d_weight, d_bias, d_conv_out, ft, d_z1, L2, d_w1, sq_partial, 1, nullptr, 0,
-                           stream);
+                           small, stream);
 }
 extern "C" int nnue_ftm_backward_bucketed(const uint8_t* bits, const float* sink, const float* d_out, const float* weight, int B, int F,
                                           int P, int L1, float* d_weight, float* d_bias, float* d_conv_out, const float* ft_grouped,
                                           const float* d_z1_grouped, int L2, float* d_w1, float* sq_partial, int K, const int32_t* seg,
-                                          int grouped_rows, nnue_stream_t stream) {
+                                          int grouped_rows, const nnue_cls_rider* small, nnue_stream_t stream) {
   NNUE_REQUIRE(K >= 1 && K <= 64, NNUE_E_ARG, "nnue_ftm_backward_bucketed: K=%d out of range", K);
   NNUE_REQUIRE(K == 1 || !d_w1 || (seg && grouped_rows >= B && grouped_rows % 16 == 0), NNUE_E_ARG,
                "nnue_ftm_backward_bucketed: d_w1 for K > 1 needs seg and the grouped row count (a multiple of 16, >= B)");
   return ftm_backward_impl(bits, sink, d_out, weight, B, F, P, L1, d_weight, d_bias, d_conv_out, ft_grouped, d_z1_grouped, L2, d_w1, sq_partial,
-                           K, K > 1 ? seg : nullptr, K > 1 ? grouped_rows : 0, stream);
+                           K, K > 1 ? seg : nullptr, K > 1 ? grouped_rows : 0, small, stream);
 }
 namespace {
 int ftm_backward_impl(const uint8_t* bits, const float* sink, const float* d_out, const float* weight, int B, int F, int P, int L1,
                       float* d_weight, float* d_bias, float* d_conv_out, const float* ft, const float* d_z1, int L2, float* d_w1,
-                      float* sq_partial, int K, const int32_t* seg, int grouped_rows, nnue_stream_t stream) {
+                      float* sq_partial, int K, const int32_t* seg, int grouped_rows, const nnue_cls_rider* small, nnue_stream_t stream) {
   NNUE_REQUIRE(bits && sink && d_out && weight && d_weight && d_bias && d_conv_out, NNUE_E_ARG, "nnue_ftm_backward: null pointer");
   const bool want_cw = d_w1 != nullptr;
   NNUE_REQUIRE(!want_cw || (ft && d_z1 && nnue_ftm_backward_cw_supported(B, F, P, L1, L2) && nnue_aligned16(ft) && nnue_aligned16(d_z1)),
@@ -1991,6 +1995,7 @@ int ftm_backward_impl(const uint8_t* bits, const float* sink, const float* d_out
   Shape sw2 = sw, sv2 = sv;
   for (Shape* q : {&sw2, &sv2}) { q->cfg = 1; q->bm = 64; q->bn = 64; q->bk = 64; }
   sw2.tiles_m = (direct + 63) / 64; sw2.tiles_n = (L1 + 63) / 64; sv2.tiles_m = (B + 63) / 64; sv2.tiles_n = (P + 63) / 64;
+  NNUE_REQUIRE(!small || pair_ok, NNUE_E_SHAPE, "nnue_ftm_backward: the classifier's small gradients can ride only in the merged launch");
   if (!pair_ok) {
     const int rc = backward_weight_impl(bits, sink, d_out, B, F, P, L1, d_weight, d_bias, sq_partial, stream);
     return rc != NNUE_OK ? rc : nnue_ftm_backward_values(bits, d_out, weight, B, F, P, L1, d_conv_out, stream);
@@ -2020,20 +2025,25 @@ int ftm_backward_impl(const uint8_t* bits, const float* sink, const float* d_out
     cw.seg = seg;
     cw.n_c = cw.per_bucket * (seg ? K : 1);
   }
-  const dim3 grid((unsigned)(n_w + n_v + cw.n_c + n_t));
+  // the classifier's small gradients + mean loss as the last tile family (nnue_classifier_train_rider filled the arguments)
+  SmallWgrad sgw{};
+  static_assert(sizeof(SmallWgrad) <= sizeof(nnue_cls_rider), "nnue_cls_rider is too small for the tile family's arguments");
+  if (small) memcpy(&sgw, small, sizeof(SmallWgrad));
+  const int n_s = small ? sgw.wgrad_blocks : 0;
+  const dim3 grid((unsigned)(n_w + n_v + cw.n_c + n_t + n_s));
 #define NNUE_FTM_BWD(WM, WN, WK, VM, VN, VK)                                                                                          \
   hipLaunchKernelGGL((ftm_backward_kernel<WM, WN, WK, VM, VN, VK>), grid, dim3(256), 0, st, wa, wb, we, direct, L1, B, swr.tiles_n, n_w, va, \
-                     vb, ve, B, P, L1, svr.tiles_n, n_v, cw, t)
+                     vb, ve, B, P, L1, svr.tiles_n, n_v, cw, t, sgw)
 #define NNUE_FTM_BWD_BF(WM, VM, VN, VK)                                                                                                  \
   do {                                                                                                                                   \
     if (w64 && WM == 64 && !v6) hipLaunchKernelGGL((ftm_backward_bf_kernel<64, VM, VN, VK, false, true>), grid, dim3(256), 0, st, wa, wb, we, direct, L1, B, \
-                               swr.tiles_n, n_w, va, vb, ve, B, P, L1, svr.tiles_n, n_v, cw, t);                                        \
+                               swr.tiles_n, n_w, va, vb, ve, B, P, L1, svr.tiles_n, n_v, cw, t, sgw);                                    \
     else if (w64 && WM == 64) hipLaunchKernelGGL((ftm_backward_bf_kernel<64, VM, VN, VK, true, true>), grid, dim3(256), 0, st, wa, wb, we, direct, L1, B, \
-                               swr.tiles_n, n_w, va, vb, ve, B, P, L1, svr.tiles_n, n_v, cw, t);                                        \
+                               swr.tiles_n, n_w, va, vb, ve, B, P, L1, svr.tiles_n, n_v, cw, t, sgw);                                    \
     else if (v6) hipLaunchKernelGGL((ftm_backward_bf_kernel<WM, VM, VN, VK, true>), grid, dim3(256), 0, st, wa, wb, we, direct, L1, B, swr.tiles_n, n_w, va, \
-                               vb, ve, B, P, L1, svr.tiles_n, n_v, cw, t);                                                               \
+                               vb, ve, B, P, L1, svr.tiles_n, n_v, cw, t, sgw);                                                           \
     else hipLaunchKernelGGL((ftm_backward_bf_kernel<WM, VM, VN, VK>), grid, dim3(256), 0, st, wa, wb, we, direct, L1, B, swr.tiles_n, n_w, va, vb, \
-                            ve, B, P, L1, svr.tiles_n, n_v, cw, t);                                                                      \
+                            ve, B, P, L1, svr.tiles_n, n_v, cw, t, sgw);                                                                  \
   } while (0)
   const bool v_small = !big_pair && sv.cfg == 0;
   const bool v6 = merged_values_bf6(B, F, P, L1);

@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -28,6 +28,15 @@ class NnueBuckets(ctypes.Structure):
 
 
 _c_bk = ctypes.POINTER(NnueBuckets)
+
+
+class NnueClsRider(ctypes.Structure):
+    """struct nnue_cls_rider of include/nnue_hip.h: the arguments of the classifier's small-gradient tile family when it rides
+    in nnue_ftm_backward's launch (opaque; filled by nnue_classifier_train_rider)."""
+    _fields_ = [("opaque", ctypes.c_ubyte * 256)]
+
+
+_c_rider = ctypes.POINTER(NnueClsRider)
 
 # name -> (restype, argtypes); mirrors include/nnue_hip.h one to one
 SIGNATURES = {
@@ -74,9 +83,11 @@ SIGNATURES = {
     "nnue_ftm_backward_cw_supported": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int]),
     "nnue_ftm_backward_sq_count": (_c_i64, [_c_int, _c_int, _c_int, _c_int]),
     "nnue_ftm_backward": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p,
-                                   _c_p, _c_p, _c_int, _c_p, _c_p, _c_p]),
+                                   _c_p, _c_p, _c_int, _c_p, _c_p, _c_rider, _c_p]),
     "nnue_ftm_backward_bucketed": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p,
-                                            _c_p, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_int, _c_p]),
+                                            _c_p, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_int, _c_rider, _c_p]),
+    "nnue_classifier_train_rider": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
+                                             _c_p, _c_p, _c_p, _c_i64, _c_bk, _c_rider]),
     "nnue_classifier_train_dz1_grouped_offset": (_c_i64, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
     "nnue_classifier_train_x_grouped_offset": (_c_i64, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
     "nnue_classifier_scratch": (_c_i64, [_c_int, _c_int, _c_int, _c_int]),
@@ -759,8 +770,9 @@ def ftm_backward_cw_supported(b: int, f: int, p: int, l1: int, l2: int) -> bool:
 def ftm_backward(d_out: torch.Tensor, weight: torch.Tensor, fm: FeatureMatrix, d_weight: Optional[torch.Tensor] = None,
                  d_bias: Optional[torch.Tensor] = None, dst: Optional[torch.Tensor] = None, ft: Optional[torch.Tensor] = None,
                  d_z1: Optional[torch.Tensor] = None, d_w1: Optional[torch.Tensor] = None,
-                 sq_partial: Optional[torch.Tensor] = None, buckets=None):
+                 sq_partial: Optional[torch.Tensor] = None, buckets=None, small: Optional["NnueClsRider"] = None):
     """(d_weight, d_bias, d_conv_out) in one launch; bitwise the results of ftm_backward_weight + ftm_backward_values.
+    small (classifier_train_rider(...)): the classifier's small gradients + mean loss run as one more tile family of the launch.
     With ft [B, L1], d_z1 [B, L2] and d_w1 [L2, L1] the launch also writes d_w1 = d_z1^T l0 (the pairwise block of ft).
     buckets (a BucketPlan): d_w1 [K, L2, L1]; ft / d_z1 are then the GROUPED-row copies [tiles*16, .] the bucketed
     classifier step left in its scratch."""
@@ -789,11 +801,28 @@ def ftm_backward(d_out: torch.Tensor, weight: torch.Tensor, fm: FeatureMatrix, d
     args = (fm.bits.data_ptr(), fm.sink.data_ptr(), d_out.data_ptr(), weight.data_ptr(), b, fm.num_rows,
             fm.positions, l1, d_weight.data_ptr(), d_bias.data_ptr(), dst.data_ptr(),
             _ptr(ft if d_w1 is not None else None), _ptr(d_z1 if d_w1 is not None else None), l2, _ptr(d_w1), _ptr(sq_partial))
+    rider = ctypes.pointer(small) if small is not None else None
     if buckets is None:
-        _call("nnue_ftm_backward", *args, _stream(d_out))
+        _call("nnue_ftm_backward", *args, rider, _stream(d_out))
     else:
-        _call("nnue_ftm_backward_bucketed", *args, buckets.K, buckets.seg.data_ptr(), rows, _stream(d_out))
+        _call("nnue_ftm_backward_bucketed", *args, buckets.K, buckets.seg.data_ptr(), rows, rider, _stream(d_out))
     return d_weight, d_bias, dst
+
+
+def classifier_train_rider(pairwise: bool, b: int, l1: int, l2: int, l3: int, c: int, h1, h2, sample_loss, loss, grads, scratch,
+                           buckets: Optional["BucketPlan"] = None) -> "NnueClsRider":
+    """Arguments of the small-gradient tile family for ftm_backward(small=...) when classifier_train_step runs with phases bit 32.
+    grads: the six classifier gradients (d_w1, d_b1, d_w2, d_b2, d_w3, d_b3) as classifier_train_step takes them.  The returned
+    struct lives on the host and holds device pointers: keep it alive as long as a recorded plan refers to it."""
+    out = NnueClsRider()
+    _, d_b1, d_w2, d_b2, d_w3, d_b3 = grads
+    rc = load().nnue_classifier_train_rider(int(bool(pairwise)), b, l1, l2, l3, c, h1.data_ptr(), h2.data_ptr(), sample_loss.data_ptr(),
+                                            loss.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(), d_b2.data_ptr(), d_w3.data_ptr(),
+                                            d_b3.data_ptr(), scratch.data_ptr(), scratch.numel(),
+                                            buckets.ref if buckets is not None else None, ctypes.byref(out))
+    if rc != 0:
+        raise NnueHipError(f"nnue_classifier_train_rider failed (code {rc}): {load().nnue_hip_last_error().decode()}")
+    return out
 
 
 # ---------------------------------------------------------------------------- bucketed layer stacks

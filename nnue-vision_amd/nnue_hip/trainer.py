@@ -27,6 +27,7 @@ SGD step) is one fixed sequence of HIP kernels here, working on preallocated buf
 """
 from __future__ import annotations
 
+import ctypes
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
@@ -348,6 +349,10 @@ class NnueTrainer:
             o_dz, o_x = lib.classifier_train_grouped_offsets(B, self.L1, self.L2, self.L3, self.C, self.K)
             self.d_z1 = self.cls_scratch[o_dz:o_dz + rows * self.L2 * 4].view(torch.float32).view(rows, self.L2)
             self.ft_rider = self.cls_scratch[o_x:o_x + rows * self.L1 * 4].view(torch.float32).view(rows, self.L1)
+        # ... and so do the classifier's small gradients + mean loss (one more tile family of that launch; the classifier's d_x
+        # launch then holds only d_x tiles).  NNUE_CLS_RIDE_SMALL=0 keeps them beside d_x.
+        self.ride_small = self.ride_dw1 and os.environ.get("NNUE_CLS_RIDE_SMALL", "1") != "0"
+        self._riders = {}  # mean-loss destination -> host struct (kept alive: recorded plans hold pointers to them)
 
     # ------------------------------------------------------------------ hyper-parameters
     # The learning rate is a device scalar (``lr_dev``) every optimizer kernel reads: changing it costs one fill and keeps
@@ -401,6 +406,17 @@ class NnueTrainer:
                                   out=(self.h1, self.h2, self.logits), loss_out=(self.sample_loss, self.loss),
                                   grads=cls_grads, d_x=self.d_ft, phases=phases, buckets=self.bucket_plan)
 
+    def _rider(self, loss: torch.Tensor):
+        """The small-gradient tile family's arguments with `loss` as the mean loss's destination (one host struct per
+        destination: step_many gives every step of a group its own)."""
+        key = loss.data_ptr()
+        if key not in self._riders:
+            g = self.g
+            grads = tuple(g[f"classifier.classifier.{i}.{n}"] for i in (0, 2, 4) for n in ("weight", "bias"))
+            self._riders[key] = lib.classifier_train_rider(True, self.B, self.L1, self.L2, self.L3, self.C, self.h1, self.h2,
+                                                           self.sample_loss, loss, grads, self.cls_scratch, self.bucket_plan)
+        return self._riders[key]
+
     def _segment(self, name: str) -> None:
         p, g = self.p, self.g
         if name == "front":
@@ -425,7 +441,7 @@ class NnueTrainer:
                 # the forward's epilogue also forms the classifier's layer-1 slabs (start of its scratch)
                 lib.ftm_forward_l1(p["input.weight"], p["input.bias"], self.fm, p["classifier.classifier.0.weight"], self.cls_scratch,
                                    out=self.ft)
-                self._cls_step(27 if self.ride_dw1 else 13)  # 27: both phases, d_w1 left to the merged backward
+                self._cls_step((59 if self.ride_small else 27) if self.ride_dw1 else 13)  # 27: both phases, d_w1 left to the merged backward; + 32: the small gradients too
                 return
             if self.use_mfma:
                 lib.ftm_forward(p["input.weight"], p["input.bias"], self.fm, out=self.ft, group=self.bucket_plan)
@@ -433,7 +449,7 @@ class NnueTrainer:
                 lib.ftb_forward(p["input.weight"], p["input.bias"], self.bits, out=self.ft)
             else:
                 lib.ft_forward(p["input.weight"], p["input.bias"], self.act, out=self.ft)
-            self._cls_step(19 if self.ride_dw1 else 5)  # 5: + the first-layer weight product beside d_x
+            self._cls_step((51 if self.ride_small else 19) if self.ride_dw1 else 5)  # 5: + the first-layer weight product beside d_x
         elif name == "ft_wgrad":
             if self.factor_exchange:
                 # this rank's share of the rows the product does not cover; they travel with the small gradients, the
@@ -449,7 +465,7 @@ class NnueTrainer:
                 lib.ftm_backward(self.d_ft, p["input.weight"], self.fm, d_weight=g["input.weight"], d_bias=g["input.bias"],
                                  dst=self.d_conv_out, ft=self.ft_rider, d_z1=self.d_z1,
                                  d_w1=g["classifier.classifier.0.weight"] if self.ride_dw1 else None, sq_partial=self.sq_partial,
-                                 buckets=self.bucket_plan)
+                                 buckets=self.bucket_plan, small=self._rider(self.loss) if self.ride_small else None)
             elif self.use_mfma:
                 lib.ftm_backward_weight(self.d_ft, self.fm, d_weight=g["input.weight"], d_bias=g["input.bias"])
             elif self.use_bits:
@@ -629,9 +645,20 @@ class NnueTrainer:
             return plan
         swap = {self.inputs[src][0].data_ptr(): self.inputs[slot][0].data_ptr(),
                 self.inputs[src][1].data_ptr(): self.inputs[slot][1].data_ptr()}
+        rider_swap = None
         if loss is not None:
             swap[self.loss.data_ptr()] = loss.data_ptr()
-        return [(nm, fn, tuple(swap.get(a, a) if isinstance(a, int) else a for a in args)) for nm, fn, args in plan]
+            if self.ride_small:  # the mean loss's destination sits inside the rider's host struct: use the struct made for `loss`
+                rider_swap = (ctypes.addressof(self._rider(self.loss)), ctypes.pointer(self._rider(loss)))
+
+        def sub(a):
+            if isinstance(a, int):
+                return swap.get(a, a)
+            if rider_swap is not None and hasattr(a, "contents") and isinstance(a.contents, lib.NnueClsRider) \
+                    and ctypes.addressof(a.contents) == rider_swap[0]:
+                return rider_swap[1]
+            return a
+        return [(nm, fn, tuple(sub(a) for a in args)) for nm, fn, args in plan]
 
     # ------------------------------------------------------------------ public
     def step(self, images: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None, slot: int = 0,
