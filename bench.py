@@ -292,20 +292,39 @@ def main():
         names = list(dict.fromkeys(names))
         merged = False
     names += ["nnue_ste_conv_backward", "nnue_sgd_step"]
+    # big table inside a step group: the update of a step also forms the next step's forward (one pass over the table); the
+    # instrumented pass then issues the group's launches eagerly (step_many(timers=...)) instead of single steps
+    group_fused = bool(getattr(trainer, "fuse_next_forward", False)) and S > 1
+    upd_fwd = f"{ftp}_backward_weight_update_forward"
+    if group_fused:
+        names += [upd_fwd]
     timers = {k: [] for k in names}
     isteps = max(5, min(50, args.steps))
-    for i in range(3):
-        trainer.step(slot=i % SLOTS, timers={k: [] for k in names})  # settle into eager mode
+    if group_fused:
+        isteps = max(S, isteps // S * S)
+        group = lambda i0: tuple((i0 + j) % SLOTS for j in range(S))  # noqa: E731
+        trainer.step_many(group(0), timers={k: [] for k in names})
+    else:
+        for i in range(3):
+            trainer.step(slot=i % SLOTS, timers={k: [] for k in names})  # settle into eager mode
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
-    for i in range(isteps):
-        trainer.step(slot=i % SLOTS, timers=timers)
+    if group_fused:
+        for i0 in range(0, isteps, S):
+            trainer.step_many(group(i0), timers=timers)
+    else:
+        for i in range(isteps):
+            trainer.step(slot=i % SLOTS, timers=timers)
     torch.cuda.synchronize(dev)
     eager_ms = (time.perf_counter() - t1) * 1e3 / isteps
     dur_us = {}
     for k, pairs in timers.items():
         # an entry point may be called more than once per step (stages / phases): report its time per step
         dur_us[k] = sum(a.elapsed_time(b) * 1e3 for a, b in pairs) / isteps if pairs else 0.0
+    if group_fused:  # these run once per group / S-1 times per group: report them per launch
+        for k in (upd_fwd, f"{ftp}_backward_weight_update", fwd_entry):
+            if timers[k]:
+                dur_us[k] = sum(a.elapsed_time(b) * 1e3 for a, b in timers[k]) / len(timers[k])
 
     row = cfg["l1"] * 4  # bytes of one gathered / accumulated table row
     alg = {  # algorithmic bytes per launch: fwd (n+1), value grad (n+1), weight grad n rows per image
@@ -322,13 +341,15 @@ def main():
     if fused_update:  # value gradient as its own launch; the weight gradient is formed inside the update product
         alg = {fwd_entry: (n_mean + 1) * row * B, f"{ftp}_backward_values": (n_mean + 1) * row * B,
                f"{ftp}_backward_weight_update": n_mean * row * B * (world if factor_exchange else 1)}
+        if group_fused:  # + the next forward's gathered rows
+            alg[upd_fwd] = n_mean * row * B + (n_mean + 1) * row * B
     kernels = {k: {"avg_us": round(dur_us[k], 2), **({"alg_GBps": round(alg[k] / dur_us[k] * 1e-3, 1)} if k in alg and dur_us[k] > 0 else {})}
                for k in names}
     KERNEL_OF = {  # C entry point -> (kernel name prefix, substring) in rocprof / PMC summaries
         "nnue_ftm_forward": ("ftm_gemm", "FwdEpi"), "nnue_ftm_forward_grouping": ("ftm_gemm", "FwdEpi"), "nnue_ftm_forward_l1": ("ftm_forward_l1", ""),
         "nnue_ftm_backward": ("ftm_backward", ""), "nnue_ftm_backward_bucketed": ("ftm_backward", ""),
         "nnue_ftm_backward_weight": ("ftm_gemm", "BwwEpi"), "nnue_ftm_backward_values": ("ftm_gemm", "ValEpi"),
-        "nnue_ftm_backward_weight_update": ("ftm_gemm", "BwwSgdEpi"),
+        "nnue_ftm_backward_weight_update": ("ftm_gemm", "BwwSgdEpi"), "nnue_ftm_backward_weight_update_forward": ("ftm_update_forward_kernel", ""),
         "nnue_ftb_forward": ("ftb_gather_kernel", ", 0,"), "nnue_ftb_backward_weight": ("ftb_gather_kernel", ", 1,"),
         "nnue_ftb_backward_values": ("ftb_values_kernel", ""), "nnue_ft_forward": ("ft_forward_wide", ""),
         "nnue_ft_backward_weight": ("ft_backward_weight_wide", ""), "nnue_ft_backward_values": ("ft_backward_values_wide", "")}
@@ -396,6 +417,9 @@ def main():
             f"{ftp}_backward_weight_update": ([("bf16", f_w * (world if factor_exchange else 1))],
                                               (mp + act) * (world if factor_exchange else 1) + 2 * tbl + (2 * tbl if OPT["momentum"] else 0)),
         }
+        # the update of step t + the forward of step t+1 in one pass: both products, the table and its momentum read and written
+        # once, both maps (the forward's own read of the table is what the fusion removes)
+        work[upd_fwd] = ([("bf16", f_w), ("bf16", f_fwd)], 2 * mp + 2 * act + 2 * tbl + (2 * tbl if OPT["momentum"] else 0))
         bw = [("bf16" if uses(2) else "f32", f_w), ("bf16x6" if uses(5) else "f32", f_v)] + ([("f32", f_l1)] if getattr(trainer, "ride_dw1", False) else [])
         work[f"{ftp}_backward"] = (bw, 2 * mp + act + F * L1 * 4.0 + tbl + B * P * 4.0)
         work[f"{ftp}_backward_bucketed"] = work[f"{ftp}_backward"]

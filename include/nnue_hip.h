@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NNUE_HIP_ABI_VERSION 29
+#define NNUE_HIP_ABI_VERSION 30
 
 #define NNUE_OK 0
 #define NNUE_E_ARG (-1)     /* null pointer, non-positive size, bad alignment */
@@ -443,6 +443,24 @@ int nnue_ftm_backward_weight_update(const uint8_t* bits, const float* d_out, int
                                     float* weight, float* momentum_rows, const float* coef,
                                     float lr, float momentum, float weight_decay, float grad_scale,
                                     int first_step, const float* lr_dev, nnue_stream_t stream);
+
+/* nnue_ftm_backward_weight_update of step t and nnue_ftm_forward of step t+1 in ONE pass over the table (inside a group of
+ * steps whose batches are already resident: the optimizer of train.py:457-464 followed by FeatureTransformer.forward,
+ * nnue.py:686-710, of the next loop iteration, train.py:359-366).  The update leaves every new table tile in registers and
+ * the next forward contracts exactly those tiles, so the forward's own read of the table (268 MB at the 224x224
+ * configuration) disappears.  bits_next / sink_next: the next batch's map (nnue_ftm_conv_binarize under the conv weights
+ * nnue_sgd_step has just updated; a different buffer than bits); bias and weight row F-1 must already hold their updated
+ * values (nnue_sgd_step applies them); out_next [B][L1]; scratch as nnue_ftm_forward (nnue_ftm_scratch bytes).  Table,
+ * momentum and out_next are BITWISE what the two separate calls produce.  Only where the forward is a split-K product
+ * over a big table (nnue_ftm_update_forward_supported: B <= 128, L1 % 64 == 0, >= 4096 table rows); NNUE_E_SHAPE otherwise. */
+int nnue_ftm_update_forward_supported(int B, int F, int P, int L1);
+/* (train.py:457-464 + nnue.py:686-710 of the next step, see above) */
+int nnue_ftm_backward_weight_update_forward(const uint8_t* bits, const float* d_out, int B, int F, int P, int L1,
+                                            float* weight, float* momentum_rows, const float* coef,
+                                            float lr, float momentum, float weight_decay, float grad_scale,
+                                            int first_step, const float* lr_dev,
+                                            const uint8_t* bits_next, const float* sink_next, const float* bias,
+                                            float* out_next, void* scratch, int64_t scratch_bytes, nnue_stream_t stream);
 
 /* Reporting only: 1 when the product of this shape runs on the bf16 matrix unit (exact three-way split of the f32
  * operand), 0 on the f32 MFMA.  which: 0 forward, 1 stand-alone weight gradient, 2 weight-gradient tiles of the merged

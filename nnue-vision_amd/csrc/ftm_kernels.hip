@@ -958,6 +958,8 @@ __global__ __launch_bounds__(256) void ftm_gemm_bf64_kernel(Mat ma, Mat mb, Epi 
   gemm_tile_bf64<128, AKC, Epi>(smem, ma, mb, epi, M, N, k_lo, (k_lo + klen < K) ? k_lo + klen : K, tiles_n, tile, ks);
 }
 
+#include "update_forward.h"  // the big table's update of step t + the forward of step t+1 in one pass over the table
+
 // ---- both operands f32 (the value gradient d_out W^T), on the bf16 matrix unit ------------------------------------------
 // Both operands are split into the three truncation planes; the six plane products whose weight is >= 2^-16
 // (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi) are accumulated, smallest first.  Left out: mid lo + lo mid (<= 2^-23 of a
@@ -2176,6 +2178,53 @@ extern "C" int nnue_ftm_backward_weight_update(const uint8_t* bits, const float*
                        BwwSgdEpi{weight, momentum == 0.0f ? nullptr : momentum_rows, coef, L1, lr, momentum, weight_decay, grad_scale, first_step, xcd, lr_dev},
                        direct, L1, B);
   return nnue_launch_status("nnue_ftm_backward_weight_update");
+}
+
+// nnue_ftm_backward_weight_update + nnue_ftm_forward of the NEXT step's map in one pass over the table (update_forward.h).
+extern "C" int nnue_ftm_update_forward_supported(int B, int F, int P, int L1) {
+  if (!nnue_ftm_supported(F, P, L1) || !shape_ok(B, F, P, L1) || B > 128 || L1 % 64 != 0) return 0;
+  const int direct = (F - 1 < P) ? F - 1 : P;
+  if (direct <= 0 || !use_bf16()) return 0;
+  // the forward must be the split-K product of 128 x 64 bf16-split tiles with 64-deep K tiles, whole 128-row table tiles per slab
+  const Shape s = plan(B, L1, direct, true, true, true);
+  static const int kt64 = env_int("NNUE_FTM_BF_KT64", 1);
+  return s.cfg == 8 && kt64 && s.ksplit > 1 && s.klen % 128 == 0 && plan(direct, L1, B, false, false, true).cfg == 8;
+}
+
+extern "C" int nnue_ftm_backward_weight_update_forward(const uint8_t* bits, const float* d_out, int B, int F, int P, int L1, float* weight,
+                                                       float* momentum_rows, const float* coef, float lr, float momentum, float weight_decay,
+                                                       float grad_scale, int first_step, const float* lr_dev, const uint8_t* bits_next,
+                                                       const float* sink_next, const float* bias, float* out_next, void* scratch,
+                                                       int64_t scratch_bytes, nnue_stream_t stream) {
+  NNUE_REQUIRE(bits && d_out && weight && coef && bits_next && sink_next && bias && out_next && scratch, NNUE_E_ARG,
+               "nnue_ftm_backward_weight_update_forward: null pointer");
+  NNUE_REQUIRE(momentum == 0.0f || momentum_rows, NNUE_E_ARG, "nnue_ftm_backward_weight_update_forward: momentum %g needs the momentum rows", momentum);
+  NNUE_REQUIRE(nnue_ftm_update_forward_supported(B, F, P, L1), NNUE_E_SHAPE,
+               "nnue_ftm_backward_weight_update_forward: B=%d F=%d P=%d L1=%d is not a split-K forward over a big table (use the two separate calls)", B,
+               F, P, L1);
+  NNUE_REQUIRE(nnue_aligned16(bits) && nnue_aligned16(bits_next) && nnue_aligned16(d_out) && nnue_aligned16(weight) && nnue_aligned16(bias) &&
+                   nnue_aligned16(out_next) && nnue_aligned16(scratch) && (!momentum_rows || nnue_aligned16(momentum_rows)),
+               NNUE_E_ARG, "nnue_ftm_backward_weight_update_forward: pointers must be 16-byte aligned");
+  NNUE_REQUIRE(bits != bits_next, NNUE_E_ARG, "nnue_ftm_backward_weight_update_forward: the two maps must be different buffers");
+  const int direct = (F - 1 < P) ? F - 1 : P;
+  const Shape s = plan(B, L1, direct, true, true, true);
+  const int64_t need = (int64_t)s.ksplit * B * L1 * (int64_t)sizeof(float);
+  NNUE_REQUIRE(scratch_bytes >= need, NNUE_E_SCRATCH, "nnue_ftm_backward_weight_update_forward: scratch %lld < %lld bytes", (long long)scratch_bytes,
+               (long long)need);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  static const int xcd = env_int("NNUE_FTM_XCD_REMAP", 1);  // developer knob
+  const int blocks = s.tiles_n * s.ksplit;
+  UpdFwd a{bits, bits_next, d_out, weight, momentum == 0.0f ? nullptr : momentum_rows, coef, lr_dev, static_cast<float*>(scratch),
+           B, P, L1, direct, s.klen, s.tiles_n, (xcd && s.ksplit % 8 == 0) ? 1 : 0, lr, momentum, weight_decay, grad_scale, env_int("NNUE_FTM_UF_ABL", 0)};
+#define NNUE_UF_LAUNCH(TWO, MOM, FIRST) hipLaunchKernelGGL((ftm_update_forward_kernel<TWO, MOM, FIRST>), dim3((unsigned)blocks), dim3(256), 0, st, a)
+  const bool two = B > 64, mom = a.momentum != nullptr, first = mom && first_step;
+  if (two) { if (!mom) NNUE_UF_LAUNCH(true, false, false); else if (first) NNUE_UF_LAUNCH(true, true, true); else NNUE_UF_LAUNCH(true, true, false); }
+  else { if (!mom) NNUE_UF_LAUNCH(false, false, false); else if (first) NNUE_UF_LAUNCH(false, true, true); else NNUE_UF_LAUNCH(false, true, false); }
+#undef NNUE_UF_LAUNCH
+  const int64_t count4 = (int64_t)B * L1 / 4;
+  hipLaunchKernelGGL(ftm_finish_kernel, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, st, static_cast<const float*>(scratch), s.ksplit, count4,
+                     bias, weight + (size_t)(F - 1) * L1, sink_next, L1, out_next);
+  return nnue_launch_status("nnue_ftm_backward_weight_update_forward");
 }
 
 // Which matrix unit a product of this shape runs on (the launch policy above, for reporting: bench.py prices a kernel

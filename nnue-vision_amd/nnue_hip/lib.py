@@ -16,7 +16,7 @@ import torch
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnnue_hip.so"
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -140,6 +140,9 @@ SIGNATURES = {
     "nnue_ftm_backward_tail_rows": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
     "nnue_ftm_backward_weight_update": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_f, _c_f, _c_f, _c_f,
                                                  _c_int, _c_p, _c_p]),
+    "nnue_ftm_update_forward_supported": (_c_int, [_c_int, _c_int, _c_int, _c_int]),
+    "nnue_ftm_backward_weight_update_forward": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_f, _c_f, _c_f, _c_f,
+                                                         _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
 }
 
 _lib: Optional[ctypes.CDLL] = None
@@ -1063,6 +1066,30 @@ def ftm_backward_weight_update(d_out: torch.Tensor, fm: "FeatureMatrix", weight:
     _call("nnue_ftm_backward_weight_update", fm.bits.data_ptr(), d_out.data_ptr(), b, fm.num_rows, fm.positions, l1, weight.data_ptr(),
           _ptr(momentum_rows), coef.data_ptr(), float(lr), float(momentum), float(weight_decay), float(grad_scale),
           int(bool(first_step)), _ptr(lr_dev), _stream(d_out))
+
+
+def ftm_update_forward_supported(batch: int, num_rows: int, positions: int, l1: int) -> bool:
+    return bool(load().nnue_ftm_update_forward_supported(int(batch), int(num_rows), int(positions), int(l1)))
+
+
+def ftm_backward_weight_update_forward(d_out: torch.Tensor, fm: "FeatureMatrix", weight: torch.Tensor,
+                                       momentum_rows: Optional[torch.Tensor], coef: torch.Tensor, lr: float, momentum: float,
+                                       weight_decay: float, grad_scale: float, first_step: bool, fm_next: "FeatureMatrix",
+                                       bias: torch.Tensor, out_next: torch.Tensor, lr_dev: Optional[torch.Tensor] = None) -> None:
+    """ftm_backward_weight_update(d_out, fm, ...) and ftm_forward(weight, bias, fm_next, out=out_next) in one pass over the
+    table (bitwise the two calls).  `bias` and table row F-1 must already be updated (sgd_step)."""
+    d_out = _need(d_out, torch.float32, "d_out")
+    b, l1 = d_out.shape
+    weight = _need(weight, torch.float32, "input.weight", (fm.num_rows, l1))
+    bias = _need(bias, torch.float32, "input.bias", (l1,))
+    out_next = _need(out_next, torch.float32, "out_next", (b, l1))
+    _need(coef, torch.float32, "clip coefficient")
+    if fm_next.batch != b or fm_next.positions != fm.positions or fm_next.num_rows != fm.num_rows:
+        raise ValueError("ftm_backward_weight_update_forward: the two maps must have the same shape")
+    _call("nnue_ftm_backward_weight_update_forward", fm.bits.data_ptr(), d_out.data_ptr(), b, fm.num_rows, fm.positions, l1,
+          weight.data_ptr(), _ptr(momentum_rows), coef.data_ptr(), float(lr), float(momentum), float(weight_decay), float(grad_scale),
+          int(bool(first_step)), _ptr(lr_dev), fm_next.bits.data_ptr(), fm_next.sink.data_ptr(), bias.data_ptr(), out_next.data_ptr(),
+          fm_next.scratch.data_ptr(), fm_next.scratch.numel(), _stream(d_out))
 
 
 class FactorExchange:

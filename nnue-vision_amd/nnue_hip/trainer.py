@@ -337,6 +337,16 @@ class NnueTrainer:
             self.gram = torch.zeros((lib.ftm_gram_scratch(self.fx.g_fm),), **f32)
             self.clip_coef = torch.ones((), **f32)
         self.grads_materialised = not (self.fuse_table_update or self.factor_exchange)
+        # Inside a step group (step_many) the table's update of step t and the FeatureTransformer forward of step t+1 are ONE
+        # pass over the table (nnue_ftm_backward_weight_update_forward: the next batch is resident, its map only needs the conv
+        # weights the small tensors' update has just written, and the update leaves every new table tile in registers) -- the
+        # forward's own 268 MB read of the table disappears.  Two maps alternate (the update still reads step t's while step
+        # t+1's is being written).  Bitwise the separate kernels.  NNUE_FUSE_NEXT_FORWARD=0 keeps them separate.
+        self.fuse_next_forward = (self.fuse_table_update and not self.fuse_l1 and self.K == 1
+                                  and os.environ.get("NNUE_FUSE_NEXT_FORWARD", "1") != "0"
+                                  and lib.ftm_update_forward_supported(B, self.F, self.P, self.L1))
+        self.fm_alt = lib.FeatureMatrix.empty(B, self.P, self.F, self.L1, self.dev) if self.fuse_next_forward else None
+        self._last_alt = False  # the last step's map is the second one (an even-length step group)
         self.d_z1 = self.ft_rider = None
         if self.ride_dw1 and self.K == 1:
             off = lib.classifier_train_dz1_offset(B, self.L1, self.L2, self.L3, self.C, True)
@@ -574,13 +584,22 @@ class NnueTrainer:
         torch.cuda.current_stream(self.dev).wait_stream(self._side)
         return graph
 
-    def _run_local(self, slot: int, part: str, main: torch.cuda.Stream, branch: bool, timers=None, loss=None) -> None:
+    def _run_local(self, slot: int, part: str, main: torch.cuda.Stream, branch: bool, timers=None, loss=None, alt: bool = False,
+                   forward_done: bool = False) -> None:
         """Launches the local segments of `part` ("all" | "a" | "b").  With `branch` (graph capture) the transposed
         lists, the FT weight gradient and the classifier weight gradients go to side streams and are joined at
         the end; otherwise everything is issued in order on `main`.  `loss`: a device scalar that receives the mean loss
         instead of ``self.loss`` (step_many's per-step results)."""
-        seg = lambda name: self._seg_plan(slot, name, loss)  # noqa: E731
+        seg = lambda name: self._seg_plan(slot, name, loss, alt)  # noqa: E731
         m = main.cuda_stream
+        if forward_done:
+            # step_many with the next forward fused into the previous step's table update: this step's map and FeatureTransformer
+            # output already exist (alt: in the second map)
+            assert part == "all" and not branch
+            lib.run_plan([c for c in seg("forward") if c[0] != "nnue_ftm_forward"], m, timers)
+            for name in ("ft_wgrad", "cls_wgrad", "tail"):
+                lib.run_plan(seg(name), m, timers)
+            return
         if part == "b":
             lib.run_plan(seg("tail"), m, timers)
             return
@@ -636,15 +655,23 @@ class NnueTrainer:
                 t.copy_(k)
         return self._plan_local, self._plan_update_first, self._plan_update
 
-    def _seg_plan(self, slot: int, name: str, loss: Optional[torch.Tensor] = None):
+    def _alt_swap(self) -> dict:
+        """Pointer substitutions that make a recorded call use the second map (fuse_next_forward)."""
+        a, b = self.fm, self.fm_alt
+        return {a.bits.data_ptr(): b.bits.data_ptr(), a.n.data_ptr(): b.n.data_ptr(), a.sink.data_ptr(): b.sink.data_ptr(),
+                a.scratch.data_ptr(): b.scratch.data_ptr()}
+
+    def _seg_plan(self, slot: int, name: str, loss: Optional[torch.Tensor] = None, alt: bool = False):
         """The recorded calls of one segment with the recorded slot's input pointers swapped for `slot`'s (and the mean
-        loss's destination for `loss`)."""
+        loss's destination for `loss`; `alt`: the map's buffers for the second map's)."""
         plan = self._plan_seg[name]
         src = self._plan_slot
-        if slot == src and loss is None:
+        if slot == src and loss is None and not alt:
             return plan
         swap = {self.inputs[src][0].data_ptr(): self.inputs[slot][0].data_ptr(),
                 self.inputs[src][1].data_ptr(): self.inputs[slot][1].data_ptr()}
+        if alt:
+            swap.update(self._alt_swap())
         rider_swap = None
         if loss is not None:
             swap[self.loss.data_ptr()] = loss.data_ptr()
@@ -697,6 +724,7 @@ class NnueTrainer:
         if ragged is None and global_count is not None and self.dp.world > 1 and int(global_count) != self.B * self.dp.world:
             ragged = self.B * self.dp.world / int(global_count)  # this rank's slot is full but others are short: the same global mean
         _, upd_first, upd = self._plans(slot)
+        self._last_alt = False
         first = self.steps_done == 0
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         graphs = self.use_graph and timers is None
@@ -788,16 +816,57 @@ class NnueTrainer:
         self.steps_done += 1
         return self.loss
 
-    def step_many(self, slots) -> torch.Tensor:
+    def _run_many(self, st: torch.cuda.Stream, slots, ring: torch.Tensor, upd, timers=None) -> None:
+        """The launches of ``len(slots)`` consecutive steps on stream `st` (the current stream): what step_many captures, and
+        -- with `timers` -- what it runs eagerly with HIP events around the named entry points."""
+        fuse = self.fuse_next_forward and len(slots) > 1 and not self.dp.collectives
+        for i, s in enumerate(slots):
+            alt = fuse and i % 2 == 1
+            self._run_local(s, "all", st, branch=False, timers=timers, loss=ring[i], alt=alt, forward_done=fuse and i > 0)
+            if self.dp.collectives:
+                with lib.time_calls(timers):
+                    self._exchange_and_update(False)
+            elif fuse and i + 1 < len(slots):
+                # small tensors (and the clip coefficient) first: the next map needs the updated conv weights and thresholds,
+                # the next forward's finish the updated bias and table row F-1
+                lib.run_plan([c for c in upd if c[0] == "nnue_sgd_step"], st.cuda_stream, timers)
+                cur, nxt = (self.fm_alt, self.fm) if alt else (self.fm, self.fm_alt)
+                lo, hi = self.sq_range
+                mom = self.flat_momentum[lo:hi] if self.flat_momentum is not None else None
+                with lib.time_calls(timers):
+                    lib.ftm_conv_binarize(self.inputs[slots[i + 1]][0], self.p["conv.weight"], self.p["visual_threshold"], self.stride,
+                                          self.F, self.L1, conv_out=self.conv_out, fm=nxt)
+                    lib.ftm_backward_weight_update_forward(self.d_ft, cur, self.p["input.weight"], mom, self.clip_coef, self.lr, self.momentum,
+                                                           self.weight_decay, self.dp.grad_scale, False, nxt, self.p["input.bias"], self.ft,
+                                                           lr_dev=self.lr_dev)
+            elif alt:
+                swap = self._alt_swap()
+                lib.run_plan([(nm, fn, tuple(swap.get(a, a) if isinstance(a, int) else a for a in args)) for nm, fn, args in upd],
+                             st.cuda_stream, timers)
+            else:
+                lib.run_plan(upd, st.cuda_stream, timers)
+
+    def step_many(self, slots, timers=None) -> torch.Tensor:
         """``len(slots)`` consecutive optimizer steps on what the named input slots already hold (fill
         ``trainer.inputs[s]`` first; a slot may repeat), replayed as ONE hipGraph: the same kernels in the same order as
         ``step(slot=s)`` for each s, without the gap between two graph launches (measured 5 us at the CIFAR batch-512
-        configuration, 5 % of its step).  Returns the mean loss of every step (device vector, no sync; a view of a ring
+        configuration, 5 % of its step).  With a big table (``fuse_next_forward``) the table update of every step but the last
+        also forms the next step's FeatureTransformer forward -- one pass over the table instead of two, bitwise the same
+        results.  Returns the mean loss of every step (device vector, no sync; a view of a ring
         the next call overwrites); ``self.loss`` is not written.  Falls back to single steps while the plans are not recorded yet, without graphs, or with an eager
-        collective."""
+        collective.  ``timers`` ({C entry point: list}): the same launches issued eagerly with HIP events around the named
+        calls (bench.py's per-kernel durations of the group form)."""
         slots = tuple(int(s) for s in slots)
         if not slots or min(slots) < 0 or max(slots) >= len(self.inputs):
             raise ValueError(f"slots must name input slots 0..{len(self.inputs) - 1}")
+        if timers is not None and self.steps_done > 0 and self._plan_local is not None and not self.dp.collectives:
+            _, _, upd = self._plans(slots[0])
+            if self.loss_ring.numel() < len(slots):
+                self.loss_ring = torch.zeros((len(slots),), dtype=torch.float32, device=self.dev)
+            self._run_many(torch.cuda.current_stream(self.dev), slots, self.loss_ring, upd, timers)
+            self._last_alt = self.fuse_next_forward and len(slots) % 2 == 0
+            self.steps_done += len(slots)
+            return self.loss_ring[:len(slots)]
         one_graph = (self.use_graph and self.steps_done > 0 and self._plan_local is not None
                      and (not self.dp.collectives or self.capture_collectives))
         if one_graph and (slots, "many") not in self._g_local:
@@ -805,17 +874,9 @@ class NnueTrainer:
             if self.loss_ring.numel() < len(slots):
                 self.loss_ring = torch.zeros((len(slots),), dtype=torch.float32, device=self.dev)
             ring = self.loss_ring
-
-            def many(st):
-                for i, s in enumerate(slots):
-                    self._run_local(s, "all", st, branch=False, loss=ring[i])
-                    if self.dp.collectives:
-                        self._exchange_and_update(False)
-                    else:
-                        lib.run_plan(upd, st.cuda_stream)
             captured = True
             try:
-                self._g_local[(slots, "many")] = (self._capture(many), ring)
+                self._g_local[(slots, "many")] = (self._capture(lambda st: self._run_many(st, slots, ring, upd)), ring)
             except RuntimeError as exc:
                 if not self.dp.collectives:
                     raise
@@ -835,6 +896,7 @@ class NnueTrainer:
             return self.loss_ring[:len(slots)]
         graph, ring = self._g_local[(slots, "many")]
         graph.replay()
+        self._last_alt = self.fuse_next_forward and len(slots) % 2 == 0 and not self.dp.collectives
         self.steps_done += len(slots)
         return ring[:len(slots)]
 
@@ -900,5 +962,6 @@ class NnueTrainer:
 
     def active_stats(self) -> Tuple[float, int]:
         """(mean, max) active features per image of the last batch -- reads back; not for timed regions."""
-        n = (self.fm if self.use_mfma else self.bits if self.use_bits else self.act).n.float()
+        fm = self.fm_alt if (self.use_mfma and self._last_alt) else self.fm
+        n = (fm if self.use_mfma else self.bits if self.use_bits else self.act).n.float()
         return float(n.mean()), int(n.max())

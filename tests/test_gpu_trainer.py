@@ -169,20 +169,31 @@ def test_first_step_on_another_slot_leaves_slot_zero_alone_and_lr_changes_take_e
     assert_close_grad(tr.evaluate(data[1][0]), ref.evaluate(data[1][0]), "evaluate after a plan recorded on slot 2", rtol=1e-6)
 
 
-@pytest.mark.parametrize("shape", ("small", "buckets"))
-def test_step_many_is_the_same_steps_in_one_graph(shape):
+@pytest.mark.parametrize("shape", ("small", "buckets", "bigtable"))
+def test_step_many_is_the_same_steps_in_one_graph(shape, monkeypatch):
     """step_many((s0, s1, ...)) replays the kernels of step(slot=s0), step(slot=s1), ... as one hipGraph: bitwise the same
     parameters, momentum and per-step losses; a learning-rate change keeps the captured graph (device scalar), a change of
-    another hyper-parameter drops it."""
+    another hyper-parameter drops it.  "bigtable": a table the forward walks as a split-K product -- inside the group the
+    table update of a step also forms the next step's FeatureTransformer forward (one pass over the table, two alternating
+    maps), still bitwise the single steps."""
     kw = dict(num_ls_buckets=4, clip_activations=1.0) if shape == "buckets" else {}
+    grid, hw, l1 = (nnue.GridFeatureSet(10, 8), 32, 256) if shape != "bigtable" else (nnue.GridFeatureSet(16, 32), 64, 256)
+    if shape == "bigtable":
+        monkeypatch.setenv("NNUE_FUSE_TABLE_UPDATE", "1")  # (auto: tables of 32 MB or more; this one has 8 MB)
+        kw = dict(input_size=64)
     torch.manual_seed(0)
-    model = nnue.NNUE(nnue.GridFeatureSet(10, 8), 256, 32, 16, num_classes=10, **kw).to(DEV)
-    twin = nnue.NNUE(nnue.GridFeatureSet(10, 8), 256, 32, 16, num_classes=10, **kw).to(DEV)
+    model = nnue.NNUE(grid, l1, 32, 16, num_classes=10, **kw).to(DEV)
+    twin = nnue.NNUE(grid, l1, 32, 16, num_classes=10, **kw).to(DEV)
     twin.load_state_dict(model.state_dict())
     gen = torch.Generator().manual_seed(5)
-    data = [(torch.randn(64, 3, 32, 32, generator=gen).to(DEV), torch.randint(0, 10, (64,), generator=gen).to(DEV)) for _ in range(3)]
+    data = [(torch.randn(64, 3, hw, hw, generator=gen).to(DEV), torch.randint(0, 10, (64,), generator=gen).to(DEV)) for _ in range(3)]
     opt = dict(lr=0.05, momentum=0.9, weight_decay=1e-4, max_grad_norm=1.0, input_slots=3, use_graph=True)
-    tr, ref = NnueTrainer(model, 64, (32, 32), **opt), NnueTrainer(twin, 64, (32, 32), **opt)
+    tr = NnueTrainer(model, 64, (hw, hw), **opt)
+    if shape == "bigtable":
+        assert tr.fuse_table_update and tr.fuse_next_forward
+        monkeypatch.setenv("NNUE_FUSE_NEXT_FORWARD", "0")
+    ref = NnueTrainer(twin, 64, (hw, hw), **opt)
+    assert not ref.fuse_next_forward
     for t in (tr, ref):
         for (im, lb), (ti, tl) in zip(data, t.inputs):
             ti.copy_(im)
@@ -208,6 +219,17 @@ def test_step_many_is_the_same_steps_in_one_graph(shape):
     assert torch.equal(got, want)
     assert torch.equal(tr.flat_params, ref.flat_params)
     assert torch.equal(tr.flat_momentum, ref.flat_momentum)
+    if shape == "bigtable":  # an even-length group ends on the second map; single steps and the statistics follow
+        got = tr.step_many(order[:4]).clone()
+        want = torch.stack([ref.step(slot=s).clone() for s in order[:4]])
+        assert torch.equal(got, want) and tr._last_alt
+        assert tr.active_stats() == ref.active_stats()
+        assert torch.equal(tr.step(slot=2), ref.step(slot=2)) and torch.equal(tr.flat_params, ref.flat_params)
+        timers = {"nnue_ftm_backward_weight_update_forward": [], "nnue_ftm_forward": []}
+        got = tr.step_many(order, timers=timers).clone()  # the same launches eagerly, with events
+        want = torch.stack([ref.step(slot=s).clone() for s in order])
+        assert torch.equal(got, want) and torch.equal(tr.flat_params, ref.flat_params)
+        assert len(timers["nnue_ftm_backward_weight_update_forward"]) == len(order) - 1 and len(timers["nnue_ftm_forward"]) == 1
     with pytest.raises(ValueError):
         tr.step_many((0, 3))
 
