@@ -281,13 +281,14 @@ def main():
     # weight + value gradient (+ tail rows) go through one C call; it is one launch at launch-sized shapes and the two
     # separate launches at the 224x224 shapes (policy in nnue_ftm_backward)
     merged = trainer.use_mfma and trainer.merge_backward
+    val_entry = "nnue_ftm_backward_values_ws" if trainer.use_mfma else f"{ftp}_backward_values"  # (the product form takes a workspace)
     bwd_entry = f"{ftp}_backward_bucketed" if (merged and trainer.K > 1) else f"{ftp}_backward"
-    names += [bwd_entry] if merged else [f"{ftp}_backward_weight", f"{ftp}_backward_values"]
+    names += [bwd_entry] if merged else [f"{ftp}_backward_weight", val_entry]
     factor_exchange = bool(getattr(trainer, "factor_exchange", False))  # data parallel: the gradient's factors are gathered, same fused update
     fused_update = bool(getattr(trainer, "fuse_table_update", False)) or factor_exchange
     if fused_update:  # weight gradient formed and consumed in the update (no d_weight)
         names = [n for n in names if n not in (f"{ftp}_backward", f"{ftp}_backward_bucketed", f"{ftp}_backward_weight")]
-        names += [f"{ftp}_backward_values", f"{ftp}_backward_tail_rows"] + (["nnue_dp_factor_pack", "nnue_dp_factor_unpack"] if factor_exchange else [])
+        names += [val_entry, f"{ftp}_backward_tail_rows"] + (["nnue_dp_factor_pack", "nnue_dp_factor_unpack"] if factor_exchange else [])
         names += [f"{ftp}_gram_sqnorm", f"{ftp}_backward_weight_update"]
         names = list(dict.fromkeys(names))
         merged = False
@@ -329,17 +330,17 @@ def main():
     row = cfg["l1"] * 4  # bytes of one gathered / accumulated table row
     alg = {  # algorithmic bytes per launch: fwd (n+1), value grad (n+1), weight grad n rows per image
         f"{ftp}_forward": (n_mean + 1) * row * B,
-        f"{ftp}_backward_values": (n_mean + 1) * row * B,
+        val_entry: (n_mean + 1) * row * B,
         f"{ftp}_backward_weight": n_mean * row * B,
     }
     if merged:
-        alg = {f"{ftp}_forward": alg[f"{ftp}_forward"], f"{ftp}_backward": alg[f"{ftp}_backward_values"] + alg[f"{ftp}_backward_weight"]}
+        alg = {f"{ftp}_forward": alg[f"{ftp}_forward"], f"{ftp}_backward": alg[val_entry] + alg[f"{ftp}_backward_weight"]}
     if fwd_entry != f"{ftp}_forward":
         alg[fwd_entry] = alg.pop(f"{ftp}_forward")
     if merged and bwd_entry != f"{ftp}_backward":
         alg[bwd_entry] = alg.pop(f"{ftp}_backward")
     if fused_update:  # value gradient as its own launch; the weight gradient is formed inside the update product
-        alg = {fwd_entry: (n_mean + 1) * row * B, f"{ftp}_backward_values": (n_mean + 1) * row * B,
+        alg = {fwd_entry: (n_mean + 1) * row * B, val_entry: (n_mean + 1) * row * B,
                f"{ftp}_backward_weight_update": n_mean * row * B * (world if factor_exchange else 1)}
         if group_fused:  # + the next forward's gathered rows
             alg[upd_fwd] = n_mean * row * B + (n_mean + 1) * row * B
@@ -348,7 +349,7 @@ def main():
     KERNEL_OF = {  # C entry point -> (kernel name prefix, substring) in rocprof / PMC summaries
         "nnue_ftm_forward": ("ftm_gemm", "FwdEpi"), "nnue_ftm_forward_grouping": ("ftm_gemm", "FwdEpi"), "nnue_ftm_forward_l1": ("ftm_forward_l1", ""),
         "nnue_ftm_backward": ("ftm_backward", ""), "nnue_ftm_backward_bucketed": ("ftm_backward", ""),
-        "nnue_ftm_backward_weight": ("ftm_gemm", "BwwEpi"), "nnue_ftm_backward_values": ("ftm_gemm", "ValEpi"),
+        "nnue_ftm_backward_weight": ("ftm_gemm", "BwwEpi"), "nnue_ftm_backward_values": ("ftm_gemm", "ValEpi"), "nnue_ftm_backward_values_ws": ("ftm_gemm", "ValEpi"),
         "nnue_ftm_backward_weight_update": ("ftm_gemm", "BwwSgdEpi"), "nnue_ftm_backward_weight_update_forward": ("ftm_update_forward_kernel", ""),
         "nnue_ftb_forward": ("ftb_gather_kernel", ", 0,"), "nnue_ftb_backward_weight": ("ftb_gather_kernel", ", 1,"),
         "nnue_ftb_backward_values": ("ftb_values_kernel", ""), "nnue_ft_forward": ("ft_forward_wide", ""),
@@ -412,7 +413,7 @@ def main():
             f"{ftp}_forward_grouping": ([("bf16" if uses(0) else "f32", f_fwd)], tbl + mp + act),
             f"{ftp}_forward_l1": ([("bf16" if uses(0) else "f32", f_fwd), ("f32", f_l1)], tbl + mp + act + (L1 // 64) * B * L2 * 4.0),
             f"{ftp}_backward_weight": ([("bf16" if uses(1) else "f32", f_w)], mp + act + tbl),
-            f"{ftp}_backward_values": ([("bf16x6" if uses(4) else "f32", f_v)], act + F * L1 * 4.0 + mp + B * P * 4.0),
+            val_entry: ([("bf16x6" if uses(4) else "f32", f_v)], act + F * L1 * 4.0 + mp + B * P * 4.0),
             # (under the factor exchange the product contracts the GLOBAL batch: world x the flops, map and d_ft rows)
             f"{ftp}_backward_weight_update": ([("bf16", f_w * (world if factor_exchange else 1))],
                                               (mp + act) * (world if factor_exchange else 1) + 2 * tbl + (2 * tbl if OPT["momentum"] else 0)),

@@ -159,3 +159,51 @@ def test_three_steps_at_the_baseline_shape_follow_the_oracle(name, expect_factor
             err, scale = float((got_d - ref_d).abs().max()), float(ref_d.abs().max())
             assert err <= 2e-4 * scale + floor, f"{name} step {s} update of {k}: err {err:.3e}, scale {scale:.3e}, floor {floor:.1e}"
     assert float(model.nnue2score) == 600.0
+
+
+def test_a_step_group_at_the_224_shape_follows_the_oracle():
+    """BASELINE configs[3]'s shape as bench.py runs it: a group of steps replayed as one hipGraph in which the table update of a
+    step also forms the next step's FeatureTransformer forward (nnue_ftm_backward_weight_update_forward, two alternating maps).
+    One single step (records the plans), then a group of three, against four oracle steps."""
+    cfg = SHAPES["c4"]
+    torch.manual_seed(0)
+    model = nnue.NNUE(nnue.GridFeatureSet(cfg["grid"], cfg["fps"]), cfg["l1"], cfg["l2"], cfg["l3"], num_classes=cfg["classes"],
+                      input_size=cfg["image"])
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    stride = orc.conv_stride(cfg["image"], cfg["grid"])
+    tr = NnueTrainer(model.to(DEV), cfg["batch"], (cfg["image"], cfg["image"]), use_graph=True, input_slots=3, **OPT)
+    import os
+    if not tr.fuse_next_forward:
+        assert os.environ.get("NNUE_FUSE_NEXT_FORWARD") == "0" or os.environ.get("NNUE_FUSE_TABLE_UPDATE") == "0" \
+            or os.environ.get("NNUE_FT_PATH", "auto") not in ("auto", "mfma") or os.environ.get("NNUE_FTM_BF16") == "0" \
+            or os.environ.get("NNUE_FTM_BF_KT64") == "0", "the 224x224 shape must take the fused pass by default"
+        pytest.skip("a knob switched the fused update + next forward off")
+    gen = torch.Generator().manual_seed(78)
+    bufs, ref_losses = {}, []
+    for s in range(4):
+        images, labels = clean_batch(cfg, params, stride, gen)
+        ref_logits, ref_loss, ref_grads, keep = orc.loss_and_grads_explicit(params, images, labels, stride, None)
+        orc.sgd_step(params, ref_grads, bufs, OPT["lr"], OPT["momentum"], OPT["weight_decay"], OPT["max_grad_norm"])
+        ref_losses.append(float(ref_loss))
+        if s == 0:
+            first = tr.step(images.to(DEV), labels.to(DEV), slot=0)
+            assert abs(float(first) - ref_losses[0]) <= 1e-4 * max(1.0, abs(ref_losses[0]))
+            was = {k: v.detach().clone() for k, v in tr.p.items()}
+            before = {k: v.clone() for k, v in params.items()}
+        else:
+            tr.inputs[s - 1][0].copy_(images)
+            tr.inputs[s - 1][1].copy_(labels)
+    losses = tr.step_many((0, 1, 2))
+    torch.cuda.synchronize()
+    assert (((0, 1, 2), "many") in tr._g_local) and tr.steps_done == 4
+    for s in range(3):
+        assert abs(float(losses[s]) - ref_losses[s + 1]) <= 1e-4 * max(1.0, abs(ref_losses[s + 1])), (s, float(losses[s]), ref_losses[s + 1])
+    assert_close_logits(tr.logits, ref_logits, "logits of the group's last step")
+    n_mean, n_max = tr.active_stats()
+    assert n_max == int(keep["n"].max()) and abs(n_mean - float(keep["n"].float().mean())) < 1e-2
+    for k in orc.TRAINABLE_KEYS:
+        assert_close_grad(tr.p[k], params[k], f"after the group: {k}", rtol=1e-5)
+        got_d, ref_d = (tr.p[k] - was[k]).cpu().double(), (params[k] - before[k]).double()
+        floor = 4 * 2.0 ** -23 * float(params[k].abs().max())
+        err, scale = float((got_d - ref_d).abs().max()), float(ref_d.abs().max())
+        assert err <= 2e-4 * scale + floor, f"three steps of {k}: err {err:.3e}, scale {scale:.3e}, floor {floor:.1e}"
