@@ -1705,7 +1705,10 @@ extern "C" int64_t nnue_ftm_scratch(int B, int F, int P, int L1) {
   if (B <= 0 || F <= 0 || P <= 0 || L1 <= 0) return 0;
   const int direct = (F - 1 < P) ? F - 1 : P;
   const Shape s = plan(B, L1, direct > 0 ? direct : 1, true, true, true);
-  return s.ksplit > 1 ? (int64_t)s.ksplit * B * L1 * (int64_t)sizeof(float) : 0;
+  if (s.ksplit <= 1) return 0;
+  // the split-K slabs; behind them room for d_out as plane images (nnue_ftm_backward_weight_update_forward: 24 KB per column
+  // tile and K tile of 64)
+  return (int64_t)s.ksplit * B * L1 * (int64_t)sizeof(float) + (int64_t)s.tiles_n * ((B + 63) / 64) * 1536 * 16;
 }
 
 extern "C" int nnue_ftm_binarize(const float* conv_out, const float* thr, int B, int fps, int Gh, int Gw, int F, uint8_t* bits,
@@ -2214,9 +2217,21 @@ extern "C" int nnue_ftm_backward_weight_update_forward(const uint8_t* bits, cons
   hipStream_t st = static_cast<hipStream_t>(stream);
   static const int xcd = env_int("NNUE_FTM_XCD_REMAP", 1);  // developer knob
   const int blocks = s.tiles_n * s.ksplit;
-  UpdFwd a{bits, bits_next, d_out, weight, momentum == 0.0f ? nullptr : momentum_rows, coef, lr_dev, static_cast<float*>(scratch),
+  // NNUE_FTM_UF_IMG=1 (developer knob): d_out split once per launch into LDS-ready plane images behind the forward's slabs in
+  // `scratch` instead of in every workgroup and table tile.  Measured at the 224x224 shape: the main kernel 222-225 vs 225-229 us,
+  // which its 2-3 us pre-pass gives back (0.476 vs 0.472 ms/step) -- a tie, so the default stays without the pre-pass.
+  static const int want_img = env_int("NNUE_FTM_UF_IMG", 0);
+  const int64_t img_bytes = (int64_t)s.tiles_n * ((B + 63) / 64) * 1536 * 16;
+  const bool img = want_img && scratch_bytes >= need + img_bytes;
+  u32x4* dimg = img ? reinterpret_cast<u32x4*>(static_cast<char*>(scratch) + need) : nullptr;
+  if (img) hipLaunchKernelGGL(uf_split_dout_kernel, dim3((unsigned)s.tiles_n, (unsigned)((B + 63) / 64)), dim3(512), 0, st, d_out, B, L1, dimg);
+  UpdFwd a{bits, bits_next, d_out, weight, momentum == 0.0f ? nullptr : momentum_rows, coef, lr_dev, static_cast<float*>(scratch), dimg,
            B, P, L1, direct, s.klen, s.tiles_n, (xcd && s.ksplit % 8 == 0) ? 1 : 0, lr, momentum, weight_decay, grad_scale, env_int("NNUE_FTM_UF_ABL", 0)};
-#define NNUE_UF_LAUNCH(TWO, MOM, FIRST) hipLaunchKernelGGL((ftm_update_forward_kernel<TWO, MOM, FIRST>), dim3((unsigned)blocks), dim3(256), 0, st, a)
+#define NNUE_UF_LAUNCH(TWO, MOM, FIRST)                                                                                                  \
+  do {                                                                                                                                   \
+    if (img) hipLaunchKernelGGL((ftm_update_forward_kernel<TWO, MOM, FIRST, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);        \
+    else hipLaunchKernelGGL((ftm_update_forward_kernel<TWO, MOM, FIRST, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);           \
+  } while (0)
   const bool two = B > 64, mom = a.momentum != nullptr, first = mom && first_step;
   if (two) { if (!mom) NNUE_UF_LAUNCH(true, false, false); else if (first) NNUE_UF_LAUNCH(true, true, true); else NNUE_UF_LAUNCH(true, true, false); }
   else { if (!mom) NNUE_UF_LAUNCH(false, false, false); else if (first) NNUE_UF_LAUNCH(false, true, true); else NNUE_UF_LAUNCH(false, true, false); }
