@@ -113,6 +113,15 @@ int nnue_ste_conv_backward(const float* images, const float* conv_out, const flo
                            const float* d_conv_out, int B, int H, int W, int fps, int stride,
                            float* d_thr, float* d_weight, void* scratch, int64_t scratch_bytes,
                            int stages, nnue_stream_t stream);
+/* The same sums (nnue.py:28-54; autograd of the conv at nnue.py:640) from the im2col form of the images that
+ * nnue_ftm_conv_binarize_patches leaves: patches [27][B*Gh*Gw] f32, term-major, read coalesced along positions instead of pixels
+ * gathered at the conv stride.  conv_out (needed only inside the threshold term's sigmoid) is read when given; with conv_out NULL
+ * it is re-formed from the patches and `weight` [fps][27] with the forward's own fmaf chain.  Either way d_thr, d_weight and the
+ * stage-1 partials are BITWISE those of nnue_ste_conv_backward.  fps <= 64. */
+int nnue_ste_conv_backward_patches(const float* patches, const float* weight, const float* conv_out, const float* thr,
+                                   const float* d_conv_out, int B, int fps, int Gh, int Gw,
+                                   float* d_thr, float* d_weight, void* scratch, int64_t scratch_bytes,
+                                   int stages, nnue_stream_t stream);
 
 /* ---- FeatureTransformer ------------------------------------------------------- */
 
@@ -217,6 +226,14 @@ int nnue_ftm_binarize(const float* conv_out, const float* thr, int B, int fps, i
 int nnue_ftm_conv_binarize(const float* images, const float* weight, const float* thr, int B, int H, int W,
                            int fps, int stride, int F, float* conv_out, uint8_t* bits, int32_t* n, float* sink,
                            nnue_stream_t stream);
+/* The same launch (nnue.py:640, :646-647, :19-25) also leaving the im2col form of the images for the backward:
+ * patches[q][b*Gh*Gw + hw] = the pixel under tap q = ci*9 + kh*3 + kw of position hw (0 where the tap falls off the image),
+ * 27*B*Gh*Gw floats.  conv_out may be NULL (not written): with a stride above 3 the taps of neighbouring positions do not
+ * overlap, the patches are a fraction of the images (0.18 at 224x224, stride 7) and the training step needs conv_out only
+ * where nnue_ste_conv_backward_patches re-forms it.  bits, n, sink (and conv_out when given) are bitwise nnue_ftm_conv_binarize's. */
+int nnue_ftm_conv_binarize_patches(const float* images, const float* weight, const float* thr, int B, int H, int W,
+                                   int fps, int stride, int F, float* patches, float* conv_out, uint8_t* bits,
+                                   int32_t* n, float* sink, nnue_stream_t stream);
 
 /* FeatureTransformer.forward for the binary map (nnue.py:686-710):
  *   out[b,:] = bias + sum_{p active, p < min(F-1,P)} weight[p,:] + sink[b] * weight[F-1,:] */

@@ -27,11 +27,16 @@ struct ConvParamsPlain {
 // kFullUnroll: all 27 taps of a channel pass unrolled (the compiler then hoists every weight read: 256 registers -- right for
 // the few-channel maps whose workgroups are latency-bound anyway); otherwise nine taps per unrolled pass (60 registers: the
 // 64-channel map of the 224x224 shape is occupancy-bound, 28.9 -> 26.4 us).
+// `patches` (or NULL): the im2col form of the images, [27][B * G] f32 term-major (patches[q][b * G + hw] = the pixel under tap q of
+// position hw, 0 where the tap falls off the image) -- what nnue_ste_conv_backward_patches reads instead of the images and of
+// conv_out; `out` may then be NULL (conv_out is not written: at stride 7 a 224x224 image is 5.4x its patches, and conv_out is
+// 2.4x them again).
 template <bool kFullUnroll, class Params, class Staged>
 __device__ __forceinline__ void conv_binarize_body(const float* __restrict__ img, Params& prm, float* __restrict__ out,
                                                    uint8_t* __restrict__ bits, int* __restrict__ n, float* __restrict__ sink, int H, int W,
                                                    int fps, int stride, int Gh, int Gw, int F, int slices, int bx, int by,
-                                                   float* __restrict__ w_lds, const Staged& staged) {
+                                                   float* __restrict__ w_lds, const Staged& staged, float* __restrict__ patches = nullptr,
+                                                   size_t patch_stride = 0) {
   // weights transposed to [27][fpad] (pad columns zero): the eight channels of a register pass are two ds_read_b128 per
   // patch term instead of eight ds_read_b32 -- the kernel was LDS-issue bound (1728 reads per thread at 64 channels);
   // thr [fpad] behind them
@@ -69,6 +74,10 @@ __device__ __forceinline__ void conv_binarize_body(const float* __restrict__ img
   int cnt = 0, snk = 0;
   for (int hw = hw0; hw < G; hw += blockDim.x * slices) {
     if (hw != hw0) load_patch(hw);
+    if (patches) {  // uniform
+#pragma unroll
+      for (int q = 0; q < 27; ++q) patches[(size_t)q * patch_stride + (size_t)b * G + hw] = patch[q];
+    }
     for (int c0 = 0; c0 < fps; c0 += kConvBinChunk) {
       float acc[kConvBinChunk];
 #pragma unroll
@@ -95,7 +104,7 @@ __device__ __forceinline__ void conv_binarize_body(const float* __restrict__ img
           const int p = (c0 + u) * G + hw;
           const size_t o = (size_t)b * fps * G + p;
           const bool on = acc[u] > thr_lds[c0 + u];
-          out[o] = acc[u];
+          if (out) out[o] = acc[u];  // uniform
           bits[o] = on ? 1 : 0;
           cnt += on;
           snk += on && p >= F - 1;

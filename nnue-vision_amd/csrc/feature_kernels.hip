@@ -63,10 +63,11 @@ __global__ __launch_bounds__(256) void conv_binarize_kernel(const float* __restr
                                                             const float* __restrict__ thr, float* __restrict__ out,
                                                             uint8_t* __restrict__ bits, int* __restrict__ n,
                                                             float* __restrict__ sink, int H, int W, int fps, int stride,
-                                                            int Gh, int Gw, int F, int slices) {
+                                                            int Gh, int Gw, int F, int slices, float* __restrict__ patches) {
   extern __shared__ __attribute__((aligned(16))) float w_lds[];
   ConvParamsPlain prm{w, thr};
-  conv_binarize_body<kFullUnroll>(img, prm, out, bits, n, sink, H, W, fps, stride, Gh, Gw, F, slices, (int)blockIdx.x, (int)blockIdx.y, w_lds, [] {});
+  conv_binarize_body<kFullUnroll>(img, prm, out, bits, n, sink, H, W, fps, stride, Gh, Gw, F, slices, (int)blockIdx.x, (int)blockIdx.y, w_lds, [] {},
+                                  patches, (size_t)gridDim.x * Gh * Gw);
 }
 
 // ------------------------------------------------------------------ binarise + compact
@@ -210,7 +211,11 @@ constexpr int kStePos = 64;     // positions per tile
 constexpr int kSteLd = 68;      // LDS row stride in floats: 16 B aligned, rows 4 banks apart -> conflict-free b128 reads
 constexpr int kSteMaxBlocks = 1024;
 
-template <int MT>  // 16-channel tiles, fps <= 16 * MT
+// kPatch: the patch terms come from the im2col buffer nnue_ftm_conv_binarize_patches wrote (`img` = patches [27][B * G], coalesced
+// along positions, instead of pixels gathered at the conv stride) and conv_out -- needed only inside the threshold term's
+// sigmoid -- is re-formed from the staged patch tile with the forward's own fmaf chain (`conv_out` = the conv weights [fps][27]):
+// bitwise the same numbers, 48 MB read per launch at the 224x224 shape instead of 160 MB.
+template <int MT, bool kPatch = false, bool kReform = false>  // 16-channel tiles, fps <= 16 * MT; kReform: conv_out = the conv weights
 __global__ __launch_bounds__(256) void ste_conv_backward_mfma(const float* __restrict__ img,
                                                               const float* __restrict__ conv_out,
                                                               const float* __restrict__ thr,
@@ -229,6 +234,8 @@ __global__ __launch_bounds__(256) void ste_conv_backward_mfma(const float* __res
   const int G = Gh * Gw;
   const int NP = B * G;
   // one tile's operands in registers: d and conv_out of this wave's channels, the wave-uniform patch terms
+  // (Requesting the workgroup's NEXT tile into a second register set before the current one is staged was measured at the
+  // 224x224 shape and loses: 40.6 vs 34.2 us from patches, 41.7 vs 39.0 us from pixels.)
   float dv[MT * 4], cvv[MT * 4], pv[7];
   auto load_tile = [&](int tile) {
     const int p = tile * kStePos + lane;
@@ -240,17 +247,21 @@ __global__ __launch_bounds__(256) void ste_conv_backward_mfma(const float* __res
       const int c = wave + 4 * j;
       const size_t o = ((size_t)b * fps + (c < fps ? c : 0)) * G + hw;
       dv[j] = (ok && c < fps) ? d_conv_out[o] : 0.0f;
-      cvv[j] = (ok && c < fps) ? conv_out[o] : 0.0f;
+      if constexpr (!kReform) cvv[j] = (ok && c < fps) ? conv_out[o] : 0.0f;
     }
     const int h = hw / Gw, x = hw - h * Gw;
 #pragma unroll
     for (int rr = 0; rr < 7; ++rr) {
       const int qq = wave + 4 * rr;  // wave-uniform patch term
       const int qc = qq < 27 ? qq : 26;
-      const int ci = qc / 9, kh = (qc - ci * 9) / 3, kw = qc - ci * 9 - kh * 3;
-      const int iy = h * stride + kh - 1, ix = x * stride + kw - 1;
-      const bool in = ok && qq < 27 && iy >= 0 && iy < H && ix >= 0 && ix < W;
-      pv[rr] = in ? img[(((size_t)b * 3 + ci) * H + iy) * W + ix] : 0.0f;
+      if constexpr (kPatch) {
+        pv[rr] = (ok && qq < 27) ? img[(size_t)qc * NP + p] : 0.0f;
+      } else {
+        const int ci = qc / 9, kh = (qc - ci * 9) / 3, kw = qc - ci * 9 - kh * 3;
+        const int iy = h * stride + kh - 1, ix = x * stride + kw - 1;
+        const bool in = ok && qq < 27 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        pv[rr] = in ? img[(((size_t)b * 3 + ci) * H + iy) * W + ix] : 0.0f;
+      }
     }
   };
   // the first tile is requested before LDS is prepared: a launch starts with cold caches
@@ -270,8 +281,10 @@ __global__ __launch_bounds__(256) void ste_conv_backward_mfma(const float* __res
     for (int j = 0; j < MT * 4; ++j) {
       const int c = wave + 4 * j;
       if (c < fps) {
-        const float s = 1.0f / (1.0f + __expf(-kSteSharpness * (cvv[j] - thr[c])));  // scalar load, cached
-        tacc[j] = fmaf(dv[j], (kSteSharpness * s) * (1.0f - s), tacc[j]);
+        if constexpr (!kReform) {
+          const float s = 1.0f / (1.0f + __expf(-kSteSharpness * (cvv[j] - thr[c])));  // scalar load, cached
+          tacc[j] = fmaf(dv[j], (kSteSharpness * s) * (1.0f - s), tacc[j]);
+        }
         d_lds[c][lane] = dv[j];
       }
     }
@@ -281,6 +294,25 @@ __global__ __launch_bounds__(256) void ste_conv_backward_mfma(const float* __res
       if (qq < 27) p_lds[qq][lane] = pv[rr];
     }
     __syncthreads();
+    if constexpr (kReform) {
+      // conv_out of this lane's position for the wave's channels: conv3x3's fmaf chain (q ascending from zero) over the staged
+      // patch column; the weights are wave-uniform (scalar loads)
+      float pq[27];
+#pragma unroll
+      for (int qq = 0; qq < 27; ++qq) pq[qq] = p_lds[qq][lane];
+#pragma unroll
+      for (int j = 0; j < MT * 4; ++j) {
+        const int c = wave + 4 * j;
+        if (c < fps) {
+          const float* __restrict__ wc = conv_out + c * 27;
+          float cv = 0.0f;
+#pragma unroll
+          for (int qq = 0; qq < 27; ++qq) cv = fmaf(pq[qq], wc[qq], cv);
+          const float s = 1.0f / (1.0f + __expf(-kSteSharpness * (cv - thr[c])));
+          tacc[j] = fmaf(dv[j], (kSteSharpness * s) * (1.0f - s), tacc[j]);
+        }
+      }
+    }
     const int k0 = 16 * wave + 4 * q;
     const float4 b0 = *reinterpret_cast<const float4*>(&p_lds[r][k0]);
     const float4 b1 = *reinterpret_cast<const float4*>(&p_lds[16 + r][k0]);
@@ -457,16 +489,16 @@ extern "C" int nnue_conv3x3_forward(const float* images, const float* weight, fl
   return nnue_launch_status("nnue_conv3x3_forward");
 }
 
-extern "C" int nnue_ftm_conv_binarize(const float* images, const float* weight, const float* thr, int B, int H, int W, int fps,
-                                      int stride, int F, float* conv_out, uint8_t* bits, int32_t* n, float* sink,
-                                      nnue_stream_t stream) {
-  NNUE_REQUIRE(images && weight && thr && conv_out && bits && n && sink, NNUE_E_ARG, "nnue_ftm_conv_binarize: null pointer");
-  NNUE_REQUIRE(B > 0 && H > 0 && W > 0 && fps > 0 && stride > 0 && F > 0, NNUE_E_ARG,
-               "nnue_ftm_conv_binarize: B=%d H=%d W=%d fps=%d stride=%d F=%d must be positive", B, H, W, fps, stride, F);
-  NNUE_REQUIRE(((fps + 7) & ~7) * 28 * 4 <= 64 * 1024, NNUE_E_SHAPE, "nnue_ftm_conv_binarize: fps=%d too large for the LDS weight tile", fps);
+namespace {
+int conv_binarize_impl(const char* who, const float* images, const float* weight, const float* thr, int B, int H, int W, int fps, int stride, int F,
+                       float* conv_out, float* patches, uint8_t* bits, int32_t* n, float* sink, nnue_stream_t stream) {
+  NNUE_REQUIRE(images && weight && thr && (conv_out || patches) && bits && n && sink, NNUE_E_ARG, "%s: null pointer", who);
+  NNUE_REQUIRE(B > 0 && H > 0 && W > 0 && fps > 0 && stride > 0 && F > 0, NNUE_E_ARG, "%s: B=%d H=%d W=%d fps=%d stride=%d F=%d must be positive", who,
+               B, H, W, fps, stride, F);
+  NNUE_REQUIRE(((fps + 7) & ~7) * 28 * 4 <= 64 * 1024, NNUE_E_SHAPE, "%s: fps=%d too large for the LDS weight tile", who, fps);
   const int Gh = (H - 1) / stride + 1, Gw = (W - 1) / stride + 1;
   const long long G = (long long)Gh * Gw;
-  NNUE_REQUIRE(G * fps < (1ll << 30) && (long long)B * G * fps < (1ll << 40), NNUE_E_SHAPE, "nnue_ftm_conv_binarize: map too large");
+  NNUE_REQUIRE(G * fps < (1ll << 30) && (long long)B * G * fps < (1ll << 40), NNUE_E_SHAPE, "%s: map too large", who);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int threads = G <= 64 ? 64 : (G <= 128 ? 128 : 256);
   // one workgroup per sample when the batch alone fills the chip; otherwise split samples (at least one position per
@@ -477,10 +509,25 @@ extern "C" int nnue_ftm_conv_binarize(const float* images, const float* weight, 
   if (slices > 1) nnue_zero_counters(n, sink, B, s);  // a kernel, not a memset node (common.h)
   const size_t lds = (size_t)(((fps + 7) & ~7) * 28) * sizeof(float);
   if (fps <= 16) hipLaunchKernelGGL(conv_binarize_kernel<true>, dim3(B, slices), dim3(threads), lds, s, images, weight, thr, conv_out, bits, n, sink, H, W, fps,
-                                    stride, Gh, Gw, F, slices);
+                                    stride, Gh, Gw, F, slices, patches);
   else hipLaunchKernelGGL(conv_binarize_kernel<false>, dim3(B, slices), dim3(threads), lds, s, images, weight, thr, conv_out, bits, n, sink, H, W, fps, stride,
-                          Gh, Gw, F, slices);
-  return nnue_launch_status("nnue_ftm_conv_binarize");
+                          Gh, Gw, F, slices, patches);
+  return nnue_launch_status(who);
+}
+}  // namespace
+
+extern "C" int nnue_ftm_conv_binarize(const float* images, const float* weight, const float* thr, int B, int H, int W, int fps,
+                                      int stride, int F, float* conv_out, uint8_t* bits, int32_t* n, float* sink,
+                                      nnue_stream_t stream) {
+  NNUE_REQUIRE(conv_out, NNUE_E_ARG, "nnue_ftm_conv_binarize: null pointer");
+  return conv_binarize_impl("nnue_ftm_conv_binarize", images, weight, thr, B, H, W, fps, stride, F, conv_out, nullptr, bits, n, sink, stream);
+}
+
+extern "C" int nnue_ftm_conv_binarize_patches(const float* images, const float* weight, const float* thr, int B, int H, int W, int fps,
+                                              int stride, int F, float* patches, float* conv_out, uint8_t* bits, int32_t* n, float* sink,
+                                              nnue_stream_t stream) {
+  NNUE_REQUIRE(patches, NNUE_E_ARG, "nnue_ftm_conv_binarize_patches: null pointer");
+  return conv_binarize_impl("nnue_ftm_conv_binarize_patches", images, weight, thr, B, H, W, fps, stride, F, conv_out, patches, bits, n, sink, stream);
 }
 
 extern "C" int nnue_binarize_features(const float* conv_out, const float* thr, int B, int fps, int Gh, int Gw, int F,
@@ -514,31 +561,36 @@ extern "C" int64_t nnue_ste_conv_backward_chunks(int B, int fps, int Gh, int Gw)
   return fps <= 64 ? ste_mfma_blocks((int64_t)B * Gh * Gw) : ste_chunks(B, fps);
 }
 
-extern "C" int nnue_ste_conv_backward(const float* images, const float* conv_out, const float* thr,
-                                      const float* d_conv_out, int B, int H, int W, int fps, int stride, float* d_thr,
-                                      float* d_weight, void* scratch, int64_t scratch_bytes, int stages, nnue_stream_t stream) {
-  NNUE_REQUIRE(images && conv_out && thr && d_conv_out && scratch, NNUE_E_ARG, "nnue_ste_conv_backward: null pointer");
-  NNUE_REQUIRE(d_thr || d_weight, NNUE_E_ARG, "nnue_ste_conv_backward: both outputs are null");
-  NNUE_REQUIRE(stages >= 1 && stages <= 3, NNUE_E_ARG, "nnue_ste_conv_backward: stages = 1 (partials) | 2 (final sums)");
-  NNUE_REQUIRE(B > 0 && H > 0 && W > 0 && fps > 0 && stride > 0, NNUE_E_ARG,
-               "nnue_ste_conv_backward: B=%d H=%d W=%d fps=%d stride=%d must be positive", B, H, W, fps, stride);
-  const int Gh = (H - 1) / stride + 1, Gw = (W - 1) / stride + 1;
-  NNUE_REQUIRE(scratch_bytes >= nnue_ste_conv_backward_scratch(B, fps, Gh, Gw), NNUE_E_SCRATCH,
-               "nnue_ste_conv_backward: scratch %lld < %lld bytes", (long long)scratch_bytes,
-               (long long)nnue_ste_conv_backward_scratch(B, fps, Gh, Gw));
+namespace {
+// patches != NULL: the im2col form (images unused, `weight` needed to re-form conv_out); else pixels + conv_out
+int ste_impl(const char* who, const float* images, const float* conv_out, const float* patches, const float* weight, const float* thr,
+             const float* d_conv_out, int B, int H, int W, int fps, int stride, int Gh, int Gw, float* d_thr, float* d_weight, void* scratch,
+             int64_t scratch_bytes, int stages, nnue_stream_t stream) {
+  NNUE_REQUIRE(d_thr || d_weight, NNUE_E_ARG, "%s: both outputs are null", who);
+  NNUE_REQUIRE(stages >= 1 && stages <= 3, NNUE_E_ARG, "%s: stages = 1 (partials) | 2 (final sums)", who);
+  NNUE_REQUIRE(scratch_bytes >= nnue_ste_conv_backward_scratch(B, fps, Gh, Gw), NNUE_E_SCRATCH, "%s: scratch %lld < %lld bytes", who,
+               (long long)scratch_bytes, (long long)nnue_ste_conv_backward_scratch(B, fps, Gh, Gw));
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* partial = static_cast<float*>(scratch);
   int chunks;
   if (fps <= 64) {
     const long long NP = (long long)B * Gh * Gw;
-    NNUE_REQUIRE(NP < (1ll << 31) - 64 && (long long)B * fps * Gh * Gw < (1ll << 40), NNUE_E_SHAPE,
-                 "nnue_ste_conv_backward: too many positions");
+    NNUE_REQUIRE(NP < (1ll << 31) - 64 && (long long)B * fps * Gh * Gw < (1ll << 40), NNUE_E_SHAPE, "%s: too many positions", who);
     const int tiles = (int)((NP + kStePos - 1) / kStePos);
     chunks = (int)ste_mfma_blocks(NP);
     if (stages & 1) {
-#define NNUE_STE_LAUNCH(MT)                                                                                              \
-  hipLaunchKernelGGL(ste_conv_backward_mfma<MT>, dim3(chunks), dim3(256), 0, s, images, conv_out, thr, d_conv_out, B, H, W, \
-                     fps, stride, Gh, Gw, tiles, partial)
+#define NNUE_STE_LAUNCH(MT)                                                                                                          \
+  do {                                                                                                                               \
+    if (patches && conv_out)                                                                                                         \
+      hipLaunchKernelGGL((ste_conv_backward_mfma<MT, true, false>), dim3(chunks), dim3(256), 0, s, patches, conv_out, thr, d_conv_out, B, H, W, \
+                         fps, stride, Gh, Gw, tiles, partial);                                                                       \
+    else if (patches)                                                                                                                \
+      hipLaunchKernelGGL((ste_conv_backward_mfma<MT, true, true>), dim3(chunks), dim3(256), 0, s, patches, weight, thr, d_conv_out, B, H, W, fps, \
+                         stride, Gh, Gw, tiles, partial);                                                                            \
+    else                                                                                                                             \
+      hipLaunchKernelGGL((ste_conv_backward_mfma<MT, false>), dim3(chunks), dim3(256), 0, s, images, conv_out, thr, d_conv_out, B, H, W, \
+                         fps, stride, Gh, Gw, tiles, partial);                                                                       \
+  } while (0)
     switch ((fps + 15) / 16) {
       case 1: NNUE_STE_LAUNCH(1); break;
       case 2: NNUE_STE_LAUNCH(2); break;
@@ -548,16 +600,39 @@ extern "C" int nnue_ste_conv_backward(const float* images, const float* conv_out
 #undef NNUE_STE_LAUNCH
     }
   } else {
+    NNUE_REQUIRE(!patches, NNUE_E_SHAPE, "%s: the im2col form needs fps <= 64 (fps = %d)", who, fps);
     chunks = ste_chunks(B, fps);
     const int spc = (B + chunks - 1) / chunks;
-    NNUE_REQUIRE((long long)spc * Gh * Gw < (1ll << 31), NNUE_E_SHAPE, "nnue_ste_conv_backward: chunk too large");
+    NNUE_REQUIRE((long long)spc * Gh * Gw < (1ll << 31), NNUE_E_SHAPE, "%s: chunk too large", who);
     if (stages & 1)
       hipLaunchKernelGGL(ste_conv_backward_stage1, dim3(fps, chunks), dim3(256), 0, s, images, conv_out, thr, d_conv_out, B, H,
                          W, fps, stride, Gh, Gw, spc, partial);
   }
   if (stages & 2)
     hipLaunchKernelGGL(ste_conv_backward_stage2, dim3((fps * 28 + 3) / 4), dim3(256), 0, s, partial, chunks, fps, d_thr, d_weight);
-  return nnue_launch_status("nnue_ste_conv_backward");
+  return nnue_launch_status(who);
+}
+}  // namespace
+
+extern "C" int nnue_ste_conv_backward(const float* images, const float* conv_out, const float* thr,
+                                      const float* d_conv_out, int B, int H, int W, int fps, int stride, float* d_thr,
+                                      float* d_weight, void* scratch, int64_t scratch_bytes, int stages, nnue_stream_t stream) {
+  NNUE_REQUIRE(images && conv_out && thr && d_conv_out && scratch, NNUE_E_ARG, "nnue_ste_conv_backward: null pointer");
+  NNUE_REQUIRE(B > 0 && H > 0 && W > 0 && fps > 0 && stride > 0, NNUE_E_ARG,
+               "nnue_ste_conv_backward: B=%d H=%d W=%d fps=%d stride=%d must be positive", B, H, W, fps, stride);
+  const int Gh = (H - 1) / stride + 1, Gw = (W - 1) / stride + 1;
+  return ste_impl("nnue_ste_conv_backward", images, conv_out, nullptr, nullptr, thr, d_conv_out, B, H, W, fps, stride, Gh, Gw, d_thr, d_weight,
+                  scratch, scratch_bytes, stages, stream);
+}
+
+extern "C" int nnue_ste_conv_backward_patches(const float* patches, const float* weight, const float* conv_out, const float* thr,
+                                              const float* d_conv_out, int B, int fps, int Gh, int Gw, float* d_thr, float* d_weight,
+                                              void* scratch, int64_t scratch_bytes, int stages, nnue_stream_t stream) {
+  NNUE_REQUIRE(patches && (weight || conv_out) && thr && d_conv_out && scratch, NNUE_E_ARG, "nnue_ste_conv_backward_patches: null pointer");
+  NNUE_REQUIRE(B > 0 && fps > 0 && Gh > 0 && Gw > 0, NNUE_E_ARG, "nnue_ste_conv_backward_patches: B=%d fps=%d Gh=%d Gw=%d must be positive", B, fps,
+               Gh, Gw);
+  return ste_impl("nnue_ste_conv_backward_patches", nullptr, conv_out, patches, weight, thr, d_conv_out, B, 0, 0, fps, 1, Gh, Gw, d_thr, d_weight,
+                  scratch, scratch_bytes, stages, stream);
 }
 
 extern "C" int nnue_conv3x3_backward_input(const float* d_conv_out, const float* weight, int B, int H, int W, int fps, int stride,

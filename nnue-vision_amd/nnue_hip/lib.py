@@ -71,6 +71,10 @@ SIGNATURES = {
     "nnue_ftm_scratch": (_c_i64, [_c_int, _c_int, _c_int, _c_int]),
     "nnue_ftm_binarize": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p]),
     "nnue_ftm_conv_binarize": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p]),
+    "nnue_ftm_conv_binarize_patches": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p,
+                                                _c_p]),
+    "nnue_ste_conv_backward_patches": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_i64, _c_int,
+                                                _c_p]),
     "nnue_ftm_forward": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_i64, _c_p]),
     "nnue_ftm_forward_grouping": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_i64, _c_p, _c_int,
                                            _c_p, _c_p, _c_p, _c_p, _c_p]),
@@ -404,6 +408,32 @@ def ste_conv_backward(images, conv_out, thr, d_conv_out, stride: int,
     return d_thr, d_weight
 
 
+def ste_conv_backward_patches(patches, weight, thr, d_conv_out, gh: int, gw: int,
+                              d_thr: Optional[torch.Tensor] = None, d_weight: Optional[torch.Tensor] = None,
+                              scratch: Optional[torch.Tensor] = None, stages: int = 3, conv_out: Optional[torch.Tensor] = None):
+    """ste_conv_backward from the im2col form ftm_conv_binarize(patches=...) left (no images; conv_out is read when given,
+    else re-formed from the patches and the conv weights); bitwise the same d_thr / d_weight / partials."""
+    weight = _need(weight, torch.float32, "conv.weight")
+    fps = weight.shape[0]
+    b = d_conv_out.numel() // (fps * gh * gw)
+    patches = _need(patches, torch.float32, "patches", (27, b * gh * gw))
+    d_conv_out = _need(d_conv_out, torch.float32, "d_conv_out").view(b, fps, gh, gw)
+    thr = _need(thr.reshape(-1), torch.float32, "threshold", (fps,))
+    dev = patches.device
+    if d_thr is None:
+        d_thr = torch.empty((fps,), dtype=torch.float32, device=dev)
+    if d_weight is None:
+        d_weight = torch.empty((fps, 3, 3, 3), dtype=torch.float32, device=dev)
+    need = load().nnue_ste_conv_backward_scratch(b, fps, gh, gw)
+    if scratch is None:
+        scratch = torch.empty((need,), dtype=torch.uint8, device=dev)
+    if conv_out is not None:
+        conv_out = _need(conv_out, torch.float32, "conv_out", (b, fps, gh, gw))
+    _call("nnue_ste_conv_backward_patches", patches.data_ptr(), weight.data_ptr(), _ptr(conv_out), thr.data_ptr(), d_conv_out.data_ptr(), b, fps, gh, gw,
+          d_thr.data_ptr(), d_weight.data_ptr(), scratch.data_ptr(), scratch.numel(), int(stages), _stream(patches))
+    return d_thr, d_weight
+
+
 def ste_conv_backward_chunks(b: int, fps: int, gh: int, gw: int) -> int:
     """Partials per output a stages=1 call leaves in its scratch."""
     return int(load().nnue_ste_conv_backward_chunks(b, fps, gh, gw))
@@ -652,8 +682,11 @@ def ftm_binarize(conv_out: torch.Tensor, thr: torch.Tensor, num_rows: int, l1: i
 
 
 def ftm_conv_binarize(images: torch.Tensor, weight: torch.Tensor, thr: torch.Tensor, stride: int, num_rows: int, l1: int,
-                      conv_out: Optional[torch.Tensor] = None, fm: Optional[FeatureMatrix] = None):
-    """conv3x3_forward + ftm_binarize in one launch; returns (conv_out, fm), bitwise the two separate calls."""
+                      conv_out: Optional[torch.Tensor] = None, fm: Optional[FeatureMatrix] = None,
+                      patches: Optional[torch.Tensor] = None, write_conv_out: bool = True):
+    """conv3x3_forward + ftm_binarize in one launch; returns (conv_out, fm), bitwise the two separate calls.
+    patches (float32 [27, B*Gh*Gw]): the launch also leaves the im2col form of the images (ste_conv_backward_patches reads
+    it); with write_conv_out=False conv_out is then not written (and None is returned in its place)."""
     images = _need(images, torch.float32, "images")
     if images.dim() != 4 or images.shape[1] != 3:
         raise ValueError(f"images: expected [B,3,H,W], got {tuple(images.shape)}")
@@ -664,7 +697,11 @@ def ftm_conv_binarize(images: torch.Tensor, weight: torch.Tensor, thr: torch.Ten
         raise ValueError("conv.weight: expected [fps,3,3,3]")
     thr = _need(thr.reshape(-1), torch.float32, "threshold", (fps,))
     gh, gw = conv_out_hw(h, w, stride)
-    if conv_out is None:
+    if patches is None and not write_conv_out:
+        raise ValueError("ftm_conv_binarize: without conv_out the patches are needed")
+    if not write_conv_out:
+        conv_out = None
+    elif conv_out is None:
         conv_out = torch.empty((b, fps, gh, gw), dtype=torch.float32, device=images.device)
     elif tuple(conv_out.shape) != (b, fps, gh, gw):
         raise ValueError("ftm_conv_binarize: conv_out has the wrong shape")
@@ -672,6 +709,11 @@ def ftm_conv_binarize(images: torch.Tensor, weight: torch.Tensor, thr: torch.Ten
         fm = FeatureMatrix.empty(b, fps * gh * gw, num_rows, l1, images.device)
     elif fm.batch != b or fm.positions != fps * gh * gw or fm.num_rows != num_rows:
         raise ValueError("ftm_conv_binarize: buffers do not match the map")
+    if patches is not None:
+        patches = _need(patches, torch.float32, "patches", (27, b * gh * gw))
+        _call("nnue_ftm_conv_binarize_patches", images.data_ptr(), weight.data_ptr(), thr.data_ptr(), b, h, w, fps, int(stride), int(num_rows),
+              patches.data_ptr(), _ptr(conv_out), fm.bits.data_ptr(), fm.n.data_ptr(), fm.sink.data_ptr(), _stream(images))
+        return conv_out, fm
     _call("nnue_ftm_conv_binarize", images.data_ptr(), weight.data_ptr(), thr.data_ptr(), b, h, w, fps, int(stride), int(num_rows),
           conv_out.data_ptr(), fm.bits.data_ptr(), fm.n.data_ptr(), fm.sink.data_ptr(), _stream(images))
     return conv_out, fm

@@ -211,11 +211,22 @@ class NnueTrainer:
                        for _ in range(max(1, input_slots))]
         self.images, self.labels = self.inputs[0]
         self.conv_out = torch.empty((B, self.fps, self.gh, self.gw), **f32)
+        self.patches = None  # (set below for the product form at large strides)
         # binary features: float {0,1} map + dense MFMA products when the shape allows, else bit masks + LDS-staged
         # gather kernels, else id lists
         self.ft_path = lib.ft_path(self.F, self.P, self.L1, B)
         self.use_mfma, self.use_bits = self.ft_path == "mfma", self.ft_path == "bits"
         self.fm = lib.FeatureMatrix.empty(B, self.P, self.F, self.L1, self.dev) if self.use_mfma else None
+        # Large strides (the taps of neighbouring positions do not overlap: 224x224 at stride 7 reads 3 of every 7 rows and the
+        # backward would gather them again): the conv launch leaves the im2col form of the images -- 27 floats per position, 0.18
+        # of the image bytes -- and does not write conv_out; the STE backward reads the patches and re-forms conv_out with the
+        # forward's fmaf chain (bitwise).  NNUE_CONV_PATCHES=0|1|auto (auto: images more than twice their patches).
+        pm = os.environ.get("NNUE_CONV_PATCHES", "auto")
+        self.reform_conv_out = os.environ.get("NNUE_CONV_REFORM", "0") == "1"  # conv_out not written; the backward re-forms it
+        self.use_patches = (self.use_mfma and self.fps <= 64 and pm != "0"
+                            and (pm == "1" or 3 * self.H * self.W > 2 * 27 * self.gh * self.gw))
+        if self.use_patches:
+            self.patches = torch.empty((27, B * self.gh * self.gw), **f32)
         # Data parallel with a bandwidth-sized table: the ranks all-gather the FACTORS of the table's gradient (the map as
         # bits + d_ft, ~1.5 MB per rank at the 224x224 shape) instead of reducing the 269 MB product, and every rank runs the
         # fused single-rank path (Gram norm, update in the product's epilogue) on the global factors: no big collective, no
@@ -432,7 +443,7 @@ class NnueTrainer:
         if name == "front":
             if self.use_mfma:  # conv + {0,1} map + counts in one launch
                 lib.ftm_conv_binarize(self.images, p["conv.weight"], p["visual_threshold"], self.stride, self.F, self.L1,
-                                      conv_out=self.conv_out, fm=self.fm)
+                                      conv_out=self.conv_out, fm=self.fm, patches=self.patches, write_conv_out=not (self.use_patches and self.reform_conv_out))
                 return
             lib.conv3x3_forward(self.images, p["conv.weight"], self.stride, out=self.conv_out)
             if self.use_bits:
@@ -494,9 +505,14 @@ class NnueTrainer:
                 lib.ftb_backward_values(self.d_ft, p["input.weight"], self.bits, dst=self.d_conv_out)
             else:
                 lib.ft_backward_values(self.d_ft, p["input.weight"], self.act, self.P, dst=self.d_conv_out)
-            lib.ste_conv_backward(self.images, self.conv_out, p["visual_threshold"], self.d_conv_out, self.stride,
-                                  d_thr=g["visual_threshold"], d_weight=g["conv.weight"], scratch=self.ste_scratch,
-                                  stages=1 if self.defer_ste else 3)
+            if self.use_patches:
+                lib.ste_conv_backward_patches(self.patches, p["conv.weight"], p["visual_threshold"], self.d_conv_out, self.gh, self.gw,
+                                              d_thr=g["visual_threshold"], d_weight=g["conv.weight"], scratch=self.ste_scratch,
+                                              stages=1 if self.defer_ste else 3, conv_out=None if self.reform_conv_out else self.conv_out)
+            else:
+                lib.ste_conv_backward(self.images, self.conv_out, p["visual_threshold"], self.d_conv_out, self.stride,
+                                      d_thr=g["visual_threshold"], d_weight=g["conv.weight"], scratch=self.ste_scratch,
+                                      stages=1 if self.defer_ste else 3)
         else:
             raise KeyError(name)
 
@@ -835,7 +851,8 @@ class NnueTrainer:
                 mom = self.flat_momentum[lo:hi] if self.flat_momentum is not None else None
                 with lib.time_calls(timers):
                     lib.ftm_conv_binarize(self.inputs[slots[i + 1]][0], self.p["conv.weight"], self.p["visual_threshold"], self.stride,
-                                          self.F, self.L1, conv_out=self.conv_out, fm=nxt)
+                                          self.F, self.L1, conv_out=self.conv_out, fm=nxt, patches=self.patches,
+                                          write_conv_out=not (self.use_patches and self.reform_conv_out))
                     lib.ftm_backward_weight_update_forward(self.d_ft, cur, self.p["input.weight"], mom, self.clip_coef, self.lr, self.momentum,
                                                            self.weight_decay, self.dp.grad_scale, False, nxt, self.p["input.bias"], self.ft,
                                                            lr_dev=self.lr_dev)
