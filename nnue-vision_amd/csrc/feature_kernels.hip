@@ -4,6 +4,8 @@
 // :590-635 (_to_sparse_features).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr float kSteSharpness = 10.0f;  // k, nnue.py:41
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(256) void ste_conv_backward_mfma(const float* __res
                                                               const float* __restrict__ thr,
                                                               const float* __restrict__ d_conv_out, int B, int H, int W,
                                                               int fps, int stride, int Gh, int Gw, int tiles,
-                                                              float* __restrict__ partial) {
+                                                              float* __restrict__ partial, int abl) {
   // staging tiles and the final cross-wave reduction buffer share LDS (the last tile ends with a barrier)
   constexpr int kStage = (MT * 16 + 32) * kSteLd, kRed = 4 * MT * 8 * 64;
   __shared__ __attribute__((aligned(16))) float smem[kStage > kRed ? kStage : kRed];
@@ -246,6 +248,9 @@ __global__ __launch_bounds__(256) void ste_conv_backward_mfma(const float* __res
     for (int j = 0; j < MT * 4; ++j) {
       const int c = wave + 4 * j;
       const size_t o = ((size_t)b * fps + (c < fps ? c : 0)) * G + hw;
+#ifdef NNUE_ABLATIONS
+      if (abl & 2) { dv[j] = 1.0f; cvv[j] = 0.5f; continue; }
+#endif
       dv[j] = (ok && c < fps) ? d_conv_out[o] : 0.0f;
       if constexpr (!kReform) cvv[j] = (ok && c < fps) ? conv_out[o] : 0.0f;
     }
@@ -254,6 +259,9 @@ __global__ __launch_bounds__(256) void ste_conv_backward_mfma(const float* __res
     for (int rr = 0; rr < 7; ++rr) {
       const int qq = wave + 4 * rr;  // wave-uniform patch term
       const int qc = qq < 27 ? qq : 26;
+#ifdef NNUE_ABLATIONS
+      if (abl & 4) { pv[rr] = 0.25f; continue; }
+#endif
       if constexpr (kPatch) {
         pv[rr] = (ok && qq < 27) ? img[(size_t)qc * NP + p] : 0.0f;
       } else {
@@ -339,7 +347,19 @@ __global__ __launch_bounds__(256) void ste_conv_backward_mfma(const float* __res
       for (int e = 0; e < 4; ++e) red[wave][(i * 2 + t) * 4 + e][lane] = acc[i][t][e];
   __syncthreads();
   // partial[(channel * 28 + term) * blocks + block]: stage 2 reads each output's partials as one contiguous run
-  float* __restrict__ out = partial + blockIdx.x;
+#ifdef NNUE_ABLATIONS
+  if (abl & 1) return;  // timing only: no partial sums written
+#endif
+  // Slot of this workgroup in every output's run of partials: workgroups of one XCD (equal blockIdx % 8) take CONSECUTIVE slots,
+  // so that the sixteen 4-byte stores that share a 64-byte line come from one L2 and leave it as one full line.  With slot =
+  // blockIdx a line was written in parts from all eight L2s -- eight masked write-backs per line: 14 of the launch's 34.6 us at
+  // the 224x224 shape (timing-only ablation without these stores: 20.3 us; profiles/r03v_ste_partials.txt).
+  int slot;
+  {
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    slot = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ((int)blockIdx.x >> 3);
+  }
+  float* __restrict__ out = partial + slot;
   const size_t os = gridDim.x;
   for (int o = threadIdx.x; o < MT * 16 * 32; o += 256) {
     const int c = o >> 5, qq = o & 31;
@@ -578,18 +598,20 @@ int ste_impl(const char* who, const float* images, const float* conv_out, const 
     NNUE_REQUIRE(NP < (1ll << 31) - 64 && (long long)B * fps * Gh * Gw < (1ll << 40), NNUE_E_SHAPE, "%s: too many positions", who);
     const int tiles = (int)((NP + kStePos - 1) / kStePos);
     chunks = (int)ste_mfma_blocks(NP);
+    const char* abl_env = std::getenv("NNUE_STE_ABL");  // timing-only ablations (NNUE_ABLATIONS builds)
+    const int abl = abl_env ? std::atoi(abl_env) : 0;
     if (stages & 1) {
 #define NNUE_STE_LAUNCH(MT)                                                                                                          \
   do {                                                                                                                               \
     if (patches && conv_out)                                                                                                         \
       hipLaunchKernelGGL((ste_conv_backward_mfma<MT, true, false>), dim3(chunks), dim3(256), 0, s, patches, conv_out, thr, d_conv_out, B, H, W, \
-                         fps, stride, Gh, Gw, tiles, partial);                                                                       \
+                         fps, stride, Gh, Gw, tiles, partial, abl);                                                                  \
     else if (patches)                                                                                                                \
       hipLaunchKernelGGL((ste_conv_backward_mfma<MT, true, true>), dim3(chunks), dim3(256), 0, s, patches, weight, thr, d_conv_out, B, H, W, fps, \
-                         stride, Gh, Gw, tiles, partial);                                                                            \
+                         stride, Gh, Gw, tiles, partial, abl);                                                                       \
     else                                                                                                                             \
       hipLaunchKernelGGL((ste_conv_backward_mfma<MT, false>), dim3(chunks), dim3(256), 0, s, images, conv_out, thr, d_conv_out, B, H, W, \
-                         fps, stride, Gh, Gw, tiles, partial);                                                                       \
+                         fps, stride, Gh, Gw, tiles, partial, abl);                                                                  \
   } while (0)
     switch ((fps + 15) / 16) {
       case 1: NNUE_STE_LAUNCH(1); break;
