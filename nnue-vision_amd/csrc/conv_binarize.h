@@ -31,7 +31,8 @@ struct ConvParamsPlain {
 // position hw, 0 where the tap falls off the image) -- what nnue_ste_conv_backward_patches reads instead of the images and of
 // conv_out; `out` may then be NULL (conv_out is not written: at stride 7 a 224x224 image is 5.4x its patches, and conv_out is
 // 2.4x them again).
-template <bool kFullUnroll, class Params, class Staged>
+// (kPatch / kOut are compile-time: as runtime pointers tests they cost the few-channel variant 7.6 -> 12.7 us at batch 1024.)
+template <bool kFullUnroll, bool kPatch, bool kOut, class Params, class Staged>
 __device__ __forceinline__ void conv_binarize_body(const float* __restrict__ img, Params& prm, float* __restrict__ out,
                                                    uint8_t* __restrict__ bits, int* __restrict__ n, float* __restrict__ sink, int H, int W,
                                                    int fps, int stride, int Gh, int Gw, int F, int slices, int bx, int by,
@@ -74,9 +75,13 @@ __device__ __forceinline__ void conv_binarize_body(const float* __restrict__ img
   int cnt = 0, snk = 0;
   for (int hw = hw0; hw < G; hw += blockDim.x * slices) {
     if (hw != hw0) load_patch(hw);
-    if (patches) {  // uniform
+    if constexpr (kPatch) {
+      // buffer stores: one 32-bit lane offset + a scalar offset per term (27 separately formed 64-bit addresses took the
+      // 64-channel variant from 60 to 198 registers)
+      const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(patches, 0, (unsigned)(27 * patch_stride * 4), 0x00020000);
+      const int vo = (b * G + hw) * 4;
 #pragma unroll
-      for (int q = 0; q < 27; ++q) patches[(size_t)q * patch_stride + (size_t)b * G + hw] = patch[q];
+      for (int q = 0; q < 27; ++q) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(patch[q]), rsp, vo, q * (int)(patch_stride * 4), 0);
     }
     for (int c0 = 0; c0 < fps; c0 += kConvBinChunk) {
       float acc[kConvBinChunk];
@@ -104,7 +109,7 @@ __device__ __forceinline__ void conv_binarize_body(const float* __restrict__ img
           const int p = (c0 + u) * G + hw;
           const size_t o = (size_t)b * fps * G + p;
           const bool on = acc[u] > thr_lds[c0 + u];
-          if (out) out[o] = acc[u];  // uniform
+          if constexpr (kOut) out[o] = acc[u];
           bits[o] = on ? 1 : 0;
           cnt += on;
           snk += on && p >= F - 1;

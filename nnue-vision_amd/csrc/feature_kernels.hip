@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void conv3x3_forward_kernel(const float* __res
 // MFMA FeatureTransformer path): conv_binarize.h.  grid (B, slices).
 #include "conv_binarize.h"
 
-template <bool kFullUnroll>
+template <bool kFullUnroll, bool kPatch = false, bool kOut = true>
 __global__ __launch_bounds__(256) void conv_binarize_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                             const float* __restrict__ thr, float* __restrict__ out,
                                                             uint8_t* __restrict__ bits, int* __restrict__ n,
@@ -68,8 +68,8 @@ __global__ __launch_bounds__(256) void conv_binarize_kernel(const float* __restr
                                                             int Gh, int Gw, int F, int slices, float* __restrict__ patches) {
   extern __shared__ __attribute__((aligned(16))) float w_lds[];
   ConvParamsPlain prm{w, thr};
-  conv_binarize_body<kFullUnroll>(img, prm, out, bits, n, sink, H, W, fps, stride, Gh, Gw, F, slices, (int)blockIdx.x, (int)blockIdx.y, w_lds, [] {},
-                                  patches, (size_t)gridDim.x * Gh * Gw);
+  conv_binarize_body<kFullUnroll, kPatch, kOut>(img, prm, out, bits, n, sink, H, W, fps, stride, Gh, Gw, F, slices, (int)blockIdx.x, (int)blockIdx.y,
+                                                w_lds, [] {}, patches, (size_t)gridDim.x * Gh * Gw);
 }
 
 // ------------------------------------------------------------------ binarise + compact
@@ -519,6 +519,7 @@ int conv_binarize_impl(const char* who, const float* images, const float* weight
   const int Gh = (H - 1) / stride + 1, Gw = (W - 1) / stride + 1;
   const long long G = (long long)Gh * Gw;
   NNUE_REQUIRE(G * fps < (1ll << 30) && (long long)B * G * fps < (1ll << 40), NNUE_E_SHAPE, "%s: map too large", who);
+  NNUE_REQUIRE(!patches || 27ll * B * G * 4 < (1ll << 31), NNUE_E_SHAPE, "%s: the im2col buffer must stay below 2 GiB", who);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int threads = G <= 64 ? 64 : (G <= 128 ? 128 : 256);
   // one workgroup per sample when the batch alone fills the chip; otherwise split samples (at least one position per
@@ -528,10 +529,19 @@ int conv_binarize_impl(const char* who, const float* images, const float* weight
   slices = slices < 1 ? 1 : (slices > 16 ? 16 : slices);
   if (slices > 1) nnue_zero_counters(n, sink, B, s);  // a kernel, not a memset node (common.h)
   const size_t lds = (size_t)(((fps + 7) & ~7) * 28) * sizeof(float);
-  if (fps <= 16) hipLaunchKernelGGL(conv_binarize_kernel<true>, dim3(B, slices), dim3(threads), lds, s, images, weight, thr, conv_out, bits, n, sink, H, W, fps,
-                                    stride, Gh, Gw, F, slices, patches);
-  else hipLaunchKernelGGL(conv_binarize_kernel<false>, dim3(B, slices), dim3(threads), lds, s, images, weight, thr, conv_out, bits, n, sink, H, W, fps, stride,
-                          Gh, Gw, F, slices, patches);
+#define NNUE_CONV_LAUNCH(FULL, PATCH, OUT)                                                                                                      \
+  hipLaunchKernelGGL((conv_binarize_kernel<FULL, PATCH, OUT>), dim3(B, slices), dim3(threads), lds, s, images, weight, thr, conv_out, bits, n, sink, H, \
+                     W, fps, stride, Gh, Gw, F, slices, patches)
+  if (fps <= 16) {
+    if (!patches) NNUE_CONV_LAUNCH(true, false, true);
+    else if (conv_out) NNUE_CONV_LAUNCH(true, true, true);
+    else NNUE_CONV_LAUNCH(true, true, false);
+  } else {
+    if (!patches) NNUE_CONV_LAUNCH(false, false, true);
+    else if (conv_out) NNUE_CONV_LAUNCH(false, true, true);
+    else NNUE_CONV_LAUNCH(false, true, false);
+  }
+#undef NNUE_CONV_LAUNCH
   return nnue_launch_status(who);
 }
 }  // namespace
