@@ -88,8 +88,9 @@ def test_trainer_with_and_without_patches_is_bitwise_the_same(monkeypatch):
         assert torch.equal(out[0][0], o[0]) and torch.equal(out[0][1], o[1])
 
 
-def test_auto_policy():
+def test_auto_policy(monkeypatch):
     """auto: the patch form where the images are more than twice their patches (224x224 at stride 7), not at the CIFAR shapes."""
+    monkeypatch.delenv("NNUE_CONV_PATCHES", raising=False)
     torch.manual_seed(0)
     small = NnueTrainer(nnue.NNUE(nnue.GridFeatureSet(10, 8), 64, 32, 8, num_classes=10).to(DEV), 8, (32, 32), lr=0.01)
     assert not small.use_patches and small.patches is None

@@ -180,6 +180,7 @@ def test_step_many_is_the_same_steps_in_one_graph(shape, monkeypatch):
     grid, hw, l1 = (nnue.GridFeatureSet(10, 8), 32, 256) if shape != "bigtable" else (nnue.GridFeatureSet(16, 32), 64, 256)
     if shape == "bigtable":
         monkeypatch.setenv("NNUE_FUSE_TABLE_UPDATE", "1")  # (auto: tables of 32 MB or more; this one has 8 MB)
+        monkeypatch.setenv("NNUE_FUSE_NEXT_FORWARD", "1")
         kw = dict(input_size=64)
     torch.manual_seed(0)
     model = nnue.NNUE(grid, l1, 32, 16, num_classes=10, **kw).to(DEV)
