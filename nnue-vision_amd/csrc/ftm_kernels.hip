@@ -209,15 +209,12 @@ struct FusedL1Pre {
 template <int BM>
 __device__ __forceinline__ void fused_l1_prefetch(const FwdL1Epi& e, FusedL1Pre<BM>& p, int m_base, int tile_n, int m0, int n0, int r,
                                                   int q, int wave) {
-  // every load unconditional (clamped index, value selected afterwards): a branch around a load makes the compiler's wait counts
-  // in the K loop that follows conservative (see gemm_tile's kDeep)
 #pragma unroll
   for (int i = 0; i < BM / 32; ++i)
 #pragma unroll
     for (int ee = 0; ee < 4; ++ee) {
       const int m = m_base + m0 + 16 * i + 4 * q + ee;
-      const float v = e.sink[m < e.B ? m : e.B - 1];
-      p.sk[i][ee] = m < e.B ? v : 0.0f;
+      p.sk[i][ee] = m < e.B ? e.sink[m] : 0.0f;
     }
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -234,8 +231,7 @@ __device__ __forceinline__ void fused_l1_prefetch(const FwdL1Epi& e, FusedL1Pre<
     for (int kb = 0; kb < 4; ++kb) {
       const int k = kb * 16 + 4 * q;  // tile-local l0 column; 4 consecutive columns stay inside one 32-column run
       const int colg = k < 32 ? tile_n * 32 + k : e.half + tile_n * 32 + (k - 32);
-      const float4 v = *reinterpret_cast<const float4*>(wrow + colg);
-      p.bq[s][kb] = jok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      p.bq[s][kb] = jok ? *reinterpret_cast<const float4*>(wrow + colg) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 }
@@ -435,11 +431,7 @@ __device__ __forceinline__ void rmw_tile(float* __restrict__ smem, const Epi& ep
 // One BM x BN output tile (linear tile index `tile`, K slab `ks`) by the 256 threads of a workgroup; `smem` is the
 // workgroup's LDS (gemm_lds_floats() floats, 16-byte aligned).
 // The tile contracts k in [k_lo, k_hi); `ks` only names the split-K slab the epilogue stores to.
-// kDeep: TWO K tiles of loads in flight (two register sets, the loop written out twice, every load unconditional -- a request past
-// k_hi gets an offset outside its window -- no branch between the halves, scheduling barriers between the sets' requests: each of
-// these was needed before the compiler's waits became vmcnt(12) instead of vmcnt(0); round 2's attempt had none of them).  With the
-// waits right it still loses at the launch-sized shapes (see nnue_ftm_forward_l1), so it stays a knob.
-template <int BM, int BN, int BK, bool AKC, bool BKC, class Epi, bool kDeep = false>
+template <int BM, int BN, int BK, bool AKC, bool BKC, class Epi>
 __device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& ma, const Mat& mb, const Epi& epi, int M, int N, int k_lo,
                                           int k_hi, int tiles_n, int tile, int ks) {
   constexpr int LDA = AKC ? BK : BM + 4, LDB = BKC ? BK : BN + 4;
@@ -474,25 +466,18 @@ __device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& m
     b_prod = n_base < epi.half;
     b_shift = b_prod ? 0 : epi.half;
   }
-  struct Regs {
-    u32x4 ra[AG], rb[BG], rb2[Epi::kBPair ? BG : 1];
-  };
-  Regs set0, set1;  // (set1: kDeep only)
-  auto fetch = [&](int k0, Regs& R) {
-    auto& ra = R.ra; auto& rb = R.rb; auto& rb2 = R.rb2;
-    // kDeep: a tile past k_hi is requested all the same; its offsets leave the operands' windows (zeros, no traffic)
-    const Mat mA = (kDeep && k0 >= k_hi) ? Mat{ma.p, ma.bytes, ma.ld, ma.clamp, 0} : ma;
-    const Mat mB = (kDeep && k0 >= k_hi) ? Mat{mb.p, mb.bytes, mb.ld, mb.clamp, 0} : mb;
+  u32x4 ra[AG], rb[BG], rb2[Epi::kBPair ? BG : 1];
+  auto fetch = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < AG; ++i)
-      ra[i] = AKC ? mat_load<AU8>(rsa, mA, m_base + a_row(i), k0 + a_k(i)) : mat_load<AU8>(rsa, mA, k0 + a_k(i), m_base + a_row(i));
+      ra[i] = AKC ? mat_load<AU8>(rsa, ma, m_base + a_row(i), k0 + a_k(i)) : mat_load<AU8>(rsa, ma, k0 + a_k(i), m_base + a_row(i));
 #pragma unroll
     for (int i = 0; i < BG; ++i)
     {
-      rb[i] = BKC ? mat_load<false>(rsb, mB, n_base + b_row(i), k0 + b_k(i))
-                  : mat_load<false>(rsb, mB, k0 + b_k(i), b_col(n_base + b_row(i)) - b_shift);
+      rb[i] = BKC ? mat_load<false>(rsb, mb, n_base + b_row(i), k0 + b_k(i))
+                  : mat_load<false>(rsb, mb, k0 + b_k(i), b_col(n_base + b_row(i)) - b_shift);
       if constexpr (Epi::kBPair)
-        if (b_prod) rb2[i] = mat_load<false>(rsb, mB, k0 + b_k(i), n_base + b_row(i) + epi.half);
+        if (b_prod) rb2[i] = mat_load<false>(rsb, mb, k0 + b_k(i), n_base + b_row(i) + epi.half);
     }
   };
   const int m0 = (wave >> 1) * (BM / 2), n0 = (wave & 1) * (BN / 2);
@@ -520,11 +505,16 @@ __device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& m
 
   FusedL1Pre<Epi::kFusedL1 ? BM : 32> l1pre;
   if constexpr (Epi::kFusedL1) fused_l1_prefetch<BM>(epi, l1pre, m_base, tile_n, m0, n0, r, q, wave);
+  // (Two K tiles of loads in flight -- two register sets, the loop written out twice, every load unconditional with a dead request's
+  // offset outside its window, no branch between the halves, scheduling barriers between the sets' requests: each of these was
+  // needed before the compiler's waits became vmcnt(12) instead of vmcnt(0), which round 2's attempt never reached -- was measured at
+  // the CIFAR batch-512 forward with the waits verified in the ISA: 20.3-20.4 us against 18.5-18.6 us.  Per-tile load latency is
+  // not what bounds the launch-sized products; the variant was removed again, the refactoring it needed cost the shipped loop 0.4 us.)
   // (Rotating the K loop per tile -- tile t starts at K tile (5 t) mod n and wraps, so that the workgroups of a launch do not all
   // walk the same 256-byte columns of the shared operands at the same time -- was measured at the CIFAR shapes and changes nothing:
   // forward 18.1 vs 18.2 us, merged backward 25.7 vs 25.4 us; profiles/r03n_krot_ab.txt.)
-  auto stage = [&](const Regs& R) {
-    const auto& ra = R.ra; const auto& rb = R.rb; const auto& rb2 = R.rb2;
+  fetch(k_lo);
+  for (int k0 = k_lo; k0 < k_hi; k0 += BK) {
 #pragma unroll
     for (int i = 0; i < AG; ++i) *reinterpret_cast<float4*>(&As[AKC ? kc(a_row(i), a_k(i)) : a_k(i) * LDA + a_row(i)]) = widen<AU8>(ra[i]);
 #pragma unroll
@@ -537,8 +527,8 @@ __device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& m
         }
       *reinterpret_cast<float4*>(&Bs[BKC ? kc(b_row(i), b_k(i)) : b_k(i) * LDB + b_row(i)]) = v;
     }
-  };
-  auto contract = [&]() {
+    __syncthreads();
+    if (k0 + BK < k_hi) fetch(k0 + BK);
     float4 a[2][TM], b[2][TN];
     frags(0, a[0], b[0]);
 #pragma unroll
@@ -566,37 +556,7 @@ __device__ __forceinline__ void gemm_tile(float* __restrict__ smem, const Mat& m
         for (int t = 0; t < TN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][i].w, b[cur][t].w, acc[i][t], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-  };
-  if constexpr (!kDeep) {
-    fetch(k_lo, set0);
-    for (int k0 = k_lo; k0 < k_hi; k0 += BK) {
-      stage(set0);
-      __syncthreads();
-      if (k0 + BK < k_hi) fetch(k0 + BK, set0);
-      contract();
-      __syncthreads();
-    }
-  } else {
-    // (the scheduling barriers keep the two sets' requests in program order: clustered by load width, set0's map words were issued
-    // after set1's table rows and the first wait of the loop had to be vmcnt(0) again)
-    fetch(k_lo, set0);
-    __builtin_amdgcn_sched_barrier(0);
-    fetch(k_lo + BK, set1);
-    __builtin_amdgcn_sched_barrier(0);
-    for (int k0 = k_lo; k0 < k_hi; k0 += 2 * BK) {
-      stage(set0);
-      __syncthreads();
-      fetch(k0 + 2 * BK, set0);
-      contract();
-      __syncthreads();
-      // (no early exit for an odd tile count: a branch between the halves merges two load histories at the loop's latch and the
-      // compiler then waits for everything again; the extra half contracts the zeros a masked request returns)
-      stage(set1);
-      __syncthreads();
-      fetch(k0 + 3 * BK, set1);
-      contract();
-      __syncthreads();
-    }
+    __syncthreads();
   }
   if constexpr (Epi::kFusedL1) {
     fused_l1_epilogue<BM>(epi, l1pre, smem, acc, m_base, tile_n, m0, n0, r, q, wave, tid);
@@ -1229,11 +1189,11 @@ __global__ __launch_bounds__(256) void ftm_gemm_kernel(Mat ma, Mat mb, Epi epi, 
   gemm_tile<BM, BN, BK, AKC, BKC, Epi>(smem, ma, mb, epi, M, N, k_lo, (k_lo + klen < K) ? k_lo + klen : K, tiles_n, blockIdx.x, blockIdx.y);
 }
 
-template <int BM, int BK, bool kDeep = false>
+template <int BM, int BK>
 __global__ __launch_bounds__(256) void ftm_forward_l1_kernel(Mat ma, Mat mb, FwdL1Epi epi, int M, int N, int K, int tiles_n) {
   constexpr int kGemm = gemm_lds_floats<BM, 64, BK, true, false>(), kEpi = 2 * BM * kL1Ld;
   __shared__ __attribute__((aligned(16))) float smem[kGemm > kEpi ? kGemm : kEpi];
-  gemm_tile<BM, 64, BK, true, false, FwdL1Epi, kDeep>(smem, ma, mb, epi, M, N, 0, K, tiles_n, blockIdx.x, 0);
+  gemm_tile<BM, 64, BK, true, false, FwdL1Epi>(smem, ma, mb, epi, M, N, 0, K, tiles_n, blockIdx.x, 0);
 }
 
 // out = bias + sink[b] * weight[F-1] + sum of the split-K slabs (fixed order)
@@ -2135,12 +2095,7 @@ extern "C" int nnue_ftm_forward_l1(const uint8_t* bits, const float* sink, const
   const Mat ma{bits, (unsigned)((size_t)B * P), P, kIntMax, kIntMax}, mb{weight, (unsigned)((size_t)direct * L1 * 4), L1, kIntMax, kIntMax};
   const FwdL1Epi epi{bias, weight + (size_t)(F - 1) * L1, sink, out, w1, part, B, L1, L2, L1 / 2};
   const dim3 grid((unsigned)(s.tiles_m * s.tiles_n));
-  // developer knob: two K tiles of loads in flight (gemm_tile's kDeep).  Measured at the CIFAR batch-512 shape with the wait counts
-  // verified in the ISA (vmcnt(12) at each stage): 20.3-20.4 us against 18.5-18.6 us -- the exposed latency per K tile is not
-  // what bounds this launch; off.
-  const bool deep = env_int("NNUE_FTM_FWD_DEEP", 0) != 0;
-  if (s.cfg == 0 && deep) hipLaunchKernelGGL((ftm_forward_l1_kernel<32, 128, true>), grid, dim3(256), 0, st, ma, mb, epi, B, L1, direct, s.tiles_n);
-  else if (s.cfg == 0) hipLaunchKernelGGL((ftm_forward_l1_kernel<32, 128>), grid, dim3(256), 0, st, ma, mb, epi, B, L1, direct, s.tiles_n);
+  if (s.cfg == 0) hipLaunchKernelGGL((ftm_forward_l1_kernel<32, 128>), grid, dim3(256), 0, st, ma, mb, epi, B, L1, direct, s.tiles_n);
   else if (s.cfg == 1) hipLaunchKernelGGL((ftm_forward_l1_kernel<64, 64>), grid, dim3(256), 0, st, ma, mb, epi, B, L1, direct, s.tiles_n);
   else if (s.cfg == 6) hipLaunchKernelGGL((ftm_forward_l1_bf_kernel<32>), grid, dim3(256), 0, st, ma, mb, epi, B, L1, direct, s.tiles_n);
   else hipLaunchKernelGGL((ftm_forward_l1_bf_kernel<64>), grid, dim3(256), 0, st, ma, mb, epi, B, L1, direct, s.tiles_n);
