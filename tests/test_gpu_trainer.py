@@ -191,6 +191,9 @@ def test_step_many_is_the_same_steps_in_one_graph(shape, monkeypatch):
     opt = dict(lr=0.05, momentum=0.9, weight_decay=1e-4, max_grad_norm=1.0, input_slots=3, use_graph=True)
     tr = NnueTrainer(model, 64, (hw, hw), **opt)
     if shape == "bigtable":
+        import os
+        if not tr.fuse_next_forward and (os.environ.get("NNUE_FTM_BF16") == "0" or os.environ.get("NNUE_FTM_BF_KT64") == "0"):
+            pytest.skip("a developer knob took the forward off the bf16-split 64-deep tiles the fused pass is built on")
         assert tr.fuse_table_update and tr.fuse_next_forward
         monkeypatch.setenv("NNUE_FUSE_NEXT_FORWARD", "0")
     ref = NnueTrainer(twin, 64, (hw, hw), **opt)
