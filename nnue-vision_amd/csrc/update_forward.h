@@ -80,8 +80,8 @@ __global__ __launch_bounds__(512) void uf_split_dout_kernel(const float* __restr
   dst[1024 + at] = pl;
 }
 
-// kTwo: B > 64, two K tiles of the weight-gradient product; kImg: d_out from the pre-split plane images; kMom: a momentum buffer; kFirst: first step (momentum is written,
-// not read).  Compile-time, and every load of the loop unconditional (a request past the workgroup's last tile is moved out
+// kTwo: B > 64, two K tiles of the weight-gradient product; kImg: d_out from the pre-split plane images; kMom: a momentum buffer;
+// kFirst: first step (momentum is written, not read).  Compile-time, and every load of the loop unconditional (a request past the workgroup's last tile is moved out
 // of its buffer window: zeros, no memory traffic), because a runtime branch around a memory instruction makes the compiler's
 // wait counts the minimum over both paths: with such branches the waits for the map tiles also drained the parameter and
 // momentum loads that had been requested after them, i.e. the HBM latency was exposed once per tile.
