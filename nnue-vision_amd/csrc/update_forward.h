@@ -81,10 +81,11 @@ __global__ __launch_bounds__(512) void uf_split_dout_kernel(const float* __restr
 }
 
 // kTwo: B > 64, two K tiles of the weight-gradient product; kImg: d_out from the pre-split plane images; kMom: a momentum buffer;
-// kFirst: first step (momentum is written, not read).  Compile-time, and every load of the loop unconditional (a request past the workgroup's last tile is moved out
-// of its buffer window: zeros, no memory traffic), because a runtime branch around a memory instruction makes the compiler's
-// wait counts the minimum over both paths: with such branches the waits for the map tiles also drained the parameter and
-// momentum loads that had been requested after them, i.e. the HBM latency was exposed once per tile.
+// kFirst: first step (momentum is written, not read).  Compile-time, and every load of the loop unconditional (a request past
+// the workgroup's last tile is moved out of its buffer window: zeros, no memory traffic), because a runtime branch around a
+// memory instruction makes the compiler's wait counts the minimum over both paths: with such branches the waits for the map
+// tiles also drained the parameter and momentum loads that had been requested after them, i.e. the HBM latency was exposed
+// once per tile.
 template <bool kTwo, bool kMom, bool kFirst, bool kImg>
 __global__ __launch_bounds__(256, 2) void ftm_update_forward_kernel(UpdFwd a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[kUfLds];
