@@ -289,7 +289,7 @@ def main():
     if fused_update:  # weight gradient formed and consumed in the update (no d_weight)
         names = [n for n in names if n not in (f"{ftp}_backward", f"{ftp}_backward_bucketed", f"{ftp}_backward_weight")]
         names += [val_entry, f"{ftp}_backward_tail_rows"] + (["nnue_dp_factor_pack", "nnue_dp_factor_unpack"] if factor_exchange else [])
-        names += [f"{ftp}_gram_sqnorm", f"{ftp}_backward_weight_update"]
+        names += [f"{ftp}_gram_sqnorm", f"{ftp}_gram_sqnorm_tail", f"{ftp}_backward_weight_update"]
         names = list(dict.fromkeys(names))
         merged = False
     names += ["nnue_ste_conv_backward", "nnue_sgd_step"]

@@ -452,6 +452,10 @@ int64_t nnue_ftm_gram_sq_count(int B, int L1);
 int64_t nnue_ftm_gram_scratch(int B, int F, int P);
 int nnue_ftm_gram_sqnorm(const uint8_t* bits, const float* d_out, int B, int F, int P, int L1,
                          float* gram, float* sq_partial, nnue_stream_t stream);
+/* nnue_ftm_gram_sqnorm with nnue_ftm_backward_tail_rows' workgroups riding in its first launch (clip_grad_norm_, train.py:363-366 +
+ * autograd of nnue.py:691, :701-708): both only read the map / d_out; the same results, one launch fewer. */
+int nnue_ftm_gram_sqnorm_tail(const uint8_t* bits, const float* sink, const float* d_out, int B, int F, int P, int L1,
+                              float* gram, float* sq_partial, float* d_weight, float* d_bias, nnue_stream_t stream);
 /* (autograd of nnue.py:691, :701-708 for the bias row and the clamp-sink row F-1) */
 int nnue_ftm_backward_tail_rows(const float* sink, const float* d_out, int B, int F, int P, int L1,
                                 float* d_weight, float* d_bias, nnue_stream_t stream);

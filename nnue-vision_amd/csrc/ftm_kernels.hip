@@ -1452,9 +1452,16 @@ __device__ __forceinline__ void gram_pair(int x, int& tm, int& tn) {  // x enume
   tn = x - tm * (tm + 1) / 2;
 }
 
+// (grid rows at and beyond `slices` carry riders: the tail rows of the table's weight gradient, nnue_ftm_gram_sqnorm_tail -- work
+// that like this product only needs d_out / the map and would otherwise be a launch of its own)
 __global__ __launch_bounds__(256) void gram_i8_kernel(const uint8_t* __restrict__ bits, unsigned bytes, int B, int P, int direct, int wave_steps,
-                                                      int* __restrict__ slabs) {
+                                                      int* __restrict__ slabs, int slices, TailRows tr, int n_tail) {
   __shared__ int red[4][4][256];
+  if ((int)blockIdx.y >= slices) {  // uniform
+    const int idx = ((int)blockIdx.y - slices) * (int)gridDim.x + (int)blockIdx.x;
+    if (idx < n_tail) tail_rows_block(tr, idx % tr.col_blocks, idx / tr.col_blocks, reinterpret_cast<float*>(&red[0][0][0]));
+    return;
+  }
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(bits), 0, bytes, 0x00020000);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2130,27 +2137,45 @@ extern "C" int64_t nnue_ftm_gram_scratch(int B, int F, int P) {
   return (int64_t)B * B + (int64_t)g.pairs * g.slices * 1024;
 }
 
-extern "C" int nnue_ftm_gram_sqnorm(const uint8_t* bits, const float* d_out, int B, int F, int P, int L1, float* gram, float* sq_partial,
-                                    nnue_stream_t stream) {
-  NNUE_REQUIRE(bits && d_out && gram && sq_partial, NNUE_E_ARG, "nnue_ftm_gram_sqnorm: null pointer");
-  NNUE_REQUIRE(shape_ok(B, F, P, L1), NNUE_E_ARG, "nnue_ftm_gram_sqnorm: B=%d F=%d P=%d L1=%d out of range", B, F, P, L1);
-  NNUE_REQUIRE(nnue_ftm_supported(F, P, L1), NNUE_E_SHAPE, "nnue_ftm_gram_sqnorm: P=%d and L1=%d must be multiples of 4", P, L1);
-  NNUE_REQUIRE(nnue_ftm_gram_sq_count(B, L1) <= 65536, NNUE_E_SHAPE, "nnue_ftm_gram_sqnorm: B=%d x L1=%d gives more than 65536 partials", B, L1);
-  NNUE_REQUIRE(nnue_aligned16(bits) && nnue_aligned16(d_out), NNUE_E_ARG, "nnue_ftm_gram_sqnorm: pointers must be 16-byte aligned");
+namespace {
+int gram_sqnorm_impl(const char* who, const uint8_t* bits, const float* sink, const float* d_out, int B, int F, int P, int L1, float* gram,
+                     float* sq_partial, float* d_weight, float* d_bias, nnue_stream_t stream) {
+  NNUE_REQUIRE(bits && d_out && gram && sq_partial, NNUE_E_ARG, "%s: null pointer", who);
+  NNUE_REQUIRE(shape_ok(B, F, P, L1), NNUE_E_ARG, "%s: B=%d F=%d P=%d L1=%d out of range", who, B, F, P, L1);
+  NNUE_REQUIRE(nnue_ftm_supported(F, P, L1), NNUE_E_SHAPE, "%s: P=%d and L1=%d must be multiples of 4", who, P, L1);
+  NNUE_REQUIRE(nnue_ftm_gram_sq_count(B, L1) <= 65536, NNUE_E_SHAPE, "%s: B=%d x L1=%d gives more than 65536 partials", who, B, L1);
+  NNUE_REQUIRE(nnue_aligned16(bits) && nnue_aligned16(d_out), NNUE_E_ARG, "%s: pointers must be 16-byte aligned", who);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int direct = (F - 1 < P) ? F - 1 : P;
   const GramPlan g = gram_plan(B, direct);
   int* slabs = reinterpret_cast<int*>(gram + (size_t)B * B);
+  const bool tail = d_weight || d_bias;
+  const TailRows tr = tail ? tail_rows(d_out, sink, B, L1, direct, F, d_weight, d_bias) : TailRows{};
+  const int n_tail = tail ? tr.col_blocks * (1 + tr.zero_slices) : 0;
   if (direct > 0) {
-    hipLaunchKernelGGL(gram_i8_kernel, dim3((unsigned)g.pairs, (unsigned)g.slices), dim3(256), 0, st, bits, (unsigned)((size_t)B * P), B, P, direct,
-                       g.wave_steps, slabs);
+    const int extra = (n_tail + g.pairs - 1) / g.pairs;  // grid rows of riders
+    hipLaunchKernelGGL(gram_i8_kernel, dim3((unsigned)g.pairs, (unsigned)(g.slices + extra)), dim3(256), 0, st, bits, (unsigned)((size_t)B * P), B, P,
+                       direct, g.wave_steps, slabs, g.slices, tr, n_tail);
     hipLaunchKernelGGL(gram_finish_kernel, dim3((unsigned)(g.pairs * 4)), dim3(256), 0, st, (const int*)slabs, g.pairs, g.slices, B, gram);
   } else {
     nnue_zero_floats(gram, (size_t)B * B, st);
+    if (tail) hipLaunchKernelGGL(ftm_tail_rows_kernel, dim3(tr.col_blocks, 1 + tr.zero_slices), dim3(256), 0, st, tr);
   }
   const int64_t tiles16 = nnue_ftm_gram_sq_count(B, L1);
   hipLaunchKernelGGL(gram_apply_kernel, dim3((unsigned)((tiles16 + 3) / 4)), dim3(256), 0, st, gram, d_out, B, L1, sq_partial);
-  return nnue_launch_status("nnue_ftm_gram_sqnorm");
+  return nnue_launch_status(who);
+}
+}  // namespace
+
+extern "C" int nnue_ftm_gram_sqnorm(const uint8_t* bits, const float* d_out, int B, int F, int P, int L1, float* gram, float* sq_partial,
+                                    nnue_stream_t stream) {
+  return gram_sqnorm_impl("nnue_ftm_gram_sqnorm", bits, nullptr, d_out, B, F, P, L1, gram, sq_partial, nullptr, nullptr, stream);
+}
+
+extern "C" int nnue_ftm_gram_sqnorm_tail(const uint8_t* bits, const float* sink, const float* d_out, int B, int F, int P, int L1, float* gram,
+                                         float* sq_partial, float* d_weight, float* d_bias, nnue_stream_t stream) {
+  NNUE_REQUIRE(sink && (d_weight || d_bias), NNUE_E_ARG, "nnue_ftm_gram_sqnorm_tail: null pointer");
+  return gram_sqnorm_impl("nnue_ftm_gram_sqnorm_tail", bits, sink, d_out, B, F, P, L1, gram, sq_partial, d_weight, d_bias, stream);
 }
 
 extern "C" int nnue_ftm_backward_tail_rows(const float* sink, const float* d_out, int B, int F, int P, int L1, float* d_weight, float* d_bias,

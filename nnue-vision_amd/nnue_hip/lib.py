@@ -141,6 +141,7 @@ SIGNATURES = {
     "nnue_ftm_gram_sq_count": (_c_i64, [_c_int, _c_int]),
     "nnue_ftm_gram_scratch": (_c_i64, [_c_int, _c_int, _c_int]),
     "nnue_ftm_gram_sqnorm": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
+    "nnue_ftm_gram_sqnorm_tail": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "nnue_ftm_backward_tail_rows": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
     "nnue_ftm_backward_weight_update": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_f, _c_f, _c_f, _c_f,
                                                  _c_int, _c_p, _c_p]),
@@ -1077,13 +1078,20 @@ def ftm_gram_scratch(fm: "FeatureMatrix") -> int:
     return int(load().nnue_ftm_gram_scratch(fm.bits.shape[0], fm.num_rows, fm.positions))
 
 
-def ftm_gram_sqnorm(fm: "FeatureMatrix", d_out: torch.Tensor, gram: torch.Tensor, sq_partial: torch.Tensor) -> torch.Tensor:
+def ftm_gram_sqnorm(fm: "FeatureMatrix", d_out: torch.Tensor, gram: torch.Tensor, sq_partial: torch.Tensor,
+                    tail=None) -> torch.Tensor:
     """Partial sums of ||A^T d_out||_F^2 over the table rows the map reaches, from two B x B Gram matrices.  ``gram``:
-    ``ftm_gram_scratch(fm)`` floats of scratch; its first B*B hold A A^T afterwards."""
+    ``ftm_gram_scratch(fm)`` floats of scratch; its first B*B hold A A^T afterwards.  tail = (d_weight, d_bias): the workgroups of
+    ftm_backward_tail_rows ride in the first launch (same results, one launch fewer)."""
     d_out = _need(d_out, torch.float32, "d_out")
     b, l1 = d_out.shape
     _need(gram, torch.float32, "gram scratch", (ftm_gram_scratch(fm),))
     _need(sq_partial, torch.float32, "gram partials", (int(load().nnue_ftm_gram_sq_count(b, l1)),))
+    if tail is not None:
+        d_weight, d_bias = tail
+        _call("nnue_ftm_gram_sqnorm_tail", fm.bits.data_ptr(), fm.sink.data_ptr(), d_out.data_ptr(), b, fm.num_rows, fm.positions, l1,
+              gram.data_ptr(), sq_partial.data_ptr(), d_weight.data_ptr(), d_bias.data_ptr(), _stream(d_out))
+        return sq_partial
     _call("nnue_ftm_gram_sqnorm", fm.bits.data_ptr(), d_out.data_ptr(), b, fm.num_rows, fm.positions, l1, gram.data_ptr(),
           sq_partial.data_ptr(), _stream(d_out))
     return sq_partial

@@ -479,8 +479,8 @@ class NnueTrainer:
             elif self.fuse_table_update:
                 # rows the product does not cover (bias, clamp-sink row, unreachable rows) + the Gram form of the norm;
                 # the product itself is part of the update (_update)
-                lib.ftm_backward_tail_rows(self.d_ft, self.fm, g["input.weight"], g["input.bias"])
-                lib.ftm_gram_sqnorm(self.fm, self.d_ft, self.gram, self.sq_partial)
+                # (the tail rows' workgroups ride in the Gram product's launch)
+                lib.ftm_gram_sqnorm(self.fm, self.d_ft, self.gram, self.sq_partial, tail=(g["input.weight"], g["input.bias"]))
             elif self.use_mfma and self.merge_backward:
                 # weight gradient, value gradient and tail rows share one launch (independent work, all read d_ft)
                 lib.ftm_backward(self.d_ft, p["input.weight"], self.fm, d_weight=g["input.weight"], d_bias=g["input.bias"],

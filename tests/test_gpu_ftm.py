@@ -384,6 +384,15 @@ def test_gram_form_of_the_weight_gradient_norm(hip, shape):
         got = float(part.double().sum())
         assert abs(got - ref) <= 2e-6 * ref, (got, ref)
     assert torch.equal(gram[:b * b].view(b, b).cpu().double(), a @ a.t())  # common active positions: exact integers
+    # the tail rows' workgroups riding in the Gram product's launch (nnue_ftm_gram_sqnorm_tail): bitwise the two separate calls
+    dw_ref, db_ref = torch.full((f, l1), 7.0, device=DEV), torch.empty(l1, device=DEV)
+    hip.ftm_backward_tail_rows(d_out.to(DEV), fm, dw_ref, db_ref)
+    dw_got, db_got = torch.full((f, l1), 7.0, device=DEV), torch.empty(l1, device=DEV)
+    gram2, part2 = torch.full_like(gram, float("nan")), torch.empty_like(part)
+    hip.ftm_gram_sqnorm(fm, d_out.to(DEV), gram2, part2, tail=(dw_got, db_got))
+    torch.cuda.synchronize()
+    assert torch.equal(part2, part) and torch.equal(gram2[:b * b], gram[:b * b])
+    assert torch.equal(dw_got, dw_ref) and torch.equal(db_got, db_ref)
 
 
 def test_table_update_in_the_product_epilogue_equals_the_materialised_path(hip, monkeypatch):
