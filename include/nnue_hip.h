@@ -472,15 +472,17 @@ int nnue_ftm_backward_weight_update(const uint8_t* bits, const float* d_out, int
  * configuration) disappears.  bits_next / sink_next: the next batch's map (nnue_ftm_conv_binarize under the conv weights
  * nnue_sgd_step has just updated; a different buffer than bits); bias and weight row F-1 must already hold their updated
  * values (nnue_sgd_step applies them); out_next [B][L1]; scratch as nnue_ftm_forward (nnue_ftm_scratch bytes).  Table,
- * momentum and out_next are BITWISE what the two separate calls produce.  Only where the forward is a split-K product
- * over a big table (nnue_ftm_update_forward_supported: B <= 128, L1 % 64 == 0, >= 4096 table rows); NNUE_E_SHAPE otherwise. */
-int nnue_ftm_update_forward_supported(int B, int F, int P, int L1);
+ * momentum and out_next are BITWISE what the two separate calls produce.  B = rows of bits / d_out (the batch -- or, under the
+ * factor exchange, the all-gathered global batch: 64, 128, 256, 512 or 1024 rows), B_next = rows of the next map and of out_next
+ * (<= 128).  Only where the forward is a split-K product over a big table (nnue_ftm_update_forward_supported: L1 % 64 == 0,
+ * >= 4096 table rows); NNUE_E_SHAPE otherwise. */
+int nnue_ftm_update_forward_supported(int B, int B_next, int F, int P, int L1);
 /* (train.py:457-464 + nnue.py:686-710 of the next step, see above) */
 int nnue_ftm_backward_weight_update_forward(const uint8_t* bits, const float* d_out, int B, int F, int P, int L1,
                                             float* weight, float* momentum_rows, const float* coef,
                                             float lr, float momentum, float weight_decay, float grad_scale,
                                             int first_step, const float* lr_dev,
-                                            const uint8_t* bits_next, const float* sink_next, const float* bias,
+                                            const uint8_t* bits_next, const float* sink_next, int B_next, const float* bias,
                                             float* out_next, void* scratch, int64_t scratch_bytes, nnue_stream_t stream);
 
 /* Reporting only: 1 when the product of this shape runs on the bf16 matrix unit (exact three-way split of the f32

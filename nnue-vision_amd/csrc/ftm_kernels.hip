@@ -1717,10 +1717,7 @@ extern "C" int64_t nnue_ftm_scratch(int B, int F, int P, int L1) {
   if (B <= 0 || F <= 0 || P <= 0 || L1 <= 0) return 0;
   const int direct = (F - 1 < P) ? F - 1 : P;
   const Shape s = plan(B, L1, direct > 0 ? direct : 1, true, true, true);
-  if (s.ksplit <= 1) return 0;
-  // the split-K slabs; behind them room for d_out as plane images (nnue_ftm_backward_weight_update_forward: 24 KB per column
-  // tile and K tile of 64)
-  return (int64_t)s.ksplit * B * L1 * (int64_t)sizeof(float) + (int64_t)s.tiles_n * ((B + 63) / 64) * 1536 * 16;
+  return s.ksplit > 1 ? (int64_t)s.ksplit * B * L1 * (int64_t)sizeof(float) : 0;
 }
 
 extern "C" int nnue_ftm_binarize(const float* conv_out, const float* thr, int B, int fps, int Gh, int Gw, int F, uint8_t* bits,
@@ -2214,12 +2211,15 @@ extern "C" int nnue_ftm_backward_weight_update(const uint8_t* bits, const float*
 }
 
 // nnue_ftm_backward_weight_update + nnue_ftm_forward of the NEXT step's map in one pass over the table (update_forward.h).
-extern "C" int nnue_ftm_update_forward_supported(int B, int F, int P, int L1) {
-  if (!nnue_ftm_supported(F, P, L1) || !shape_ok(B, F, P, L1) || B > 128 || L1 % 64 != 0) return 0;
+// B: rows of the gradient's factors (the batch, or the global batch under the factor exchange); B_next: rows of the next map.
+extern "C" int nnue_ftm_update_forward_supported(int B, int B_next, int F, int P, int L1) {
+  if (!nnue_ftm_supported(F, P, L1) || !shape_ok(B, F, P, L1) || B_next <= 0 || B_next > 128 || L1 % 64 != 0) return 0;
+  const int nk = (B + 63) / 64;  // K tiles of the weight-gradient product: 1, 2, 4, 8 or 16
+  if (nk > 16 || (nk & (nk - 1)) != 0) return 0;
   const int direct = (F - 1 < P) ? F - 1 : P;
   if (direct <= 0 || !use_bf16()) return 0;
   // the forward must be the split-K product of 128 x 64 bf16-split tiles with 64-deep K tiles, whole 128-row table tiles per slab
-  const Shape s = plan(B, L1, direct, true, true, true);
+  const Shape s = plan(B_next, L1, direct, true, true, true);
   static const int kt64 = env_int("NNUE_FTM_BF_KT64", 1);
   return s.cfg == 8 && kt64 && s.ksplit > 1 && s.klen % 128 == 0 && plan(direct, L1, B, false, false, true).cfg == 8;
 }
@@ -2227,46 +2227,44 @@ extern "C" int nnue_ftm_update_forward_supported(int B, int F, int P, int L1) {
 extern "C" int nnue_ftm_backward_weight_update_forward(const uint8_t* bits, const float* d_out, int B, int F, int P, int L1, float* weight,
                                                        float* momentum_rows, const float* coef, float lr, float momentum, float weight_decay,
                                                        float grad_scale, int first_step, const float* lr_dev, const uint8_t* bits_next,
-                                                       const float* sink_next, const float* bias, float* out_next, void* scratch,
+                                                       const float* sink_next, int B_next, const float* bias, float* out_next, void* scratch,
                                                        int64_t scratch_bytes, nnue_stream_t stream) {
   NNUE_REQUIRE(bits && d_out && weight && coef && bits_next && sink_next && bias && out_next && scratch, NNUE_E_ARG,
                "nnue_ftm_backward_weight_update_forward: null pointer");
   NNUE_REQUIRE(momentum == 0.0f || momentum_rows, NNUE_E_ARG, "nnue_ftm_backward_weight_update_forward: momentum %g needs the momentum rows", momentum);
-  NNUE_REQUIRE(nnue_ftm_update_forward_supported(B, F, P, L1), NNUE_E_SHAPE,
-               "nnue_ftm_backward_weight_update_forward: B=%d F=%d P=%d L1=%d is not a split-K forward over a big table (use the two separate calls)", B,
-               F, P, L1);
+  NNUE_REQUIRE(nnue_ftm_update_forward_supported(B, B_next, F, P, L1), NNUE_E_SHAPE,
+               "nnue_ftm_backward_weight_update_forward: B=%d B_next=%d F=%d P=%d L1=%d is not a split-K forward over a big table (use the two separate "
+               "calls)", B, B_next, F, P, L1);
   NNUE_REQUIRE(nnue_aligned16(bits) && nnue_aligned16(bits_next) && nnue_aligned16(d_out) && nnue_aligned16(weight) && nnue_aligned16(bias) &&
                    nnue_aligned16(out_next) && nnue_aligned16(scratch) && (!momentum_rows || nnue_aligned16(momentum_rows)),
                NNUE_E_ARG, "nnue_ftm_backward_weight_update_forward: pointers must be 16-byte aligned");
   NNUE_REQUIRE(bits != bits_next, NNUE_E_ARG, "nnue_ftm_backward_weight_update_forward: the two maps must be different buffers");
   const int direct = (F - 1 < P) ? F - 1 : P;
-  const Shape s = plan(B, L1, direct, true, true, true);
-  const int64_t need = (int64_t)s.ksplit * B * L1 * (int64_t)sizeof(float);
+  const Shape s = plan(B_next, L1, direct, true, true, true);
+  const int64_t need = (int64_t)s.ksplit * B_next * L1 * (int64_t)sizeof(float);
   NNUE_REQUIRE(scratch_bytes >= need, NNUE_E_SCRATCH, "nnue_ftm_backward_weight_update_forward: scratch %lld < %lld bytes", (long long)scratch_bytes,
                (long long)need);
   hipStream_t st = static_cast<hipStream_t>(stream);
   static const int xcd = env_int("NNUE_FTM_XCD_REMAP", 1);  // developer knob
   const int blocks = s.tiles_n * s.ksplit;
-  // NNUE_FTM_UF_IMG=1 (developer knob): d_out split once per launch into LDS-ready plane images behind the forward's slabs in
-  // `scratch` instead of in every workgroup and table tile.  Measured at the 224x224 shape: the main kernel 222-225 vs 225-229 us,
-  // which its 2-3 us pre-pass gives back (0.476 vs 0.472 ms/step) -- a tie, so the default stays without the pre-pass.
-  static const int want_img = env_int("NNUE_FTM_UF_IMG", 0);
-  const int64_t img_bytes = (int64_t)s.tiles_n * ((B + 63) / 64) * 1536 * 16;
-  const bool img = want_img && scratch_bytes >= need + img_bytes;
-  u32x4* dimg = img ? reinterpret_cast<u32x4*>(static_cast<char*>(scratch) + need) : nullptr;
-  if (img) hipLaunchKernelGGL(uf_split_dout_kernel, dim3((unsigned)s.tiles_n, (unsigned)((B + 63) / 64)), dim3(512), 0, st, d_out, B, L1, dimg);
-  UpdFwd a{bits, bits_next, d_out, weight, momentum == 0.0f ? nullptr : momentum_rows, coef, lr_dev, static_cast<float*>(scratch), dimg,
-           B, P, L1, direct, s.klen, s.tiles_n, (xcd && s.ksplit % 8 == 0) ? 1 : 0, lr, momentum, weight_decay, grad_scale, env_int("NNUE_FTM_UF_ABL", 0)};
-#define NNUE_UF_LAUNCH(TWO, MOM, FIRST)                                                                                                  \
-  do {                                                                                                                                   \
-    if (img) hipLaunchKernelGGL((ftm_update_forward_kernel<TWO, MOM, FIRST, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);        \
-    else hipLaunchKernelGGL((ftm_update_forward_kernel<TWO, MOM, FIRST, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);           \
+  UpdFwd a{bits, bits_next, d_out, weight, momentum == 0.0f ? nullptr : momentum_rows, coef, lr_dev, static_cast<float*>(scratch),
+           B, B_next, P, L1, direct, s.klen, s.tiles_n, (xcd && s.ksplit % 8 == 0) ? 1 : 0, lr, momentum, weight_decay, grad_scale, env_int("NNUE_FTM_UF_ABL", 0)};
+  const bool mom = a.momentum != nullptr, first = mom && first_step;
+#define NNUE_UF_LAUNCH(NK)                                                                                                         \
+  do {                                                                                                                             \
+    if (!mom) hipLaunchKernelGGL((ftm_update_forward_kernel<NK, false, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);      \
+    else if (first) hipLaunchKernelGGL((ftm_update_forward_kernel<NK, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);  \
+    else hipLaunchKernelGGL((ftm_update_forward_kernel<NK, true, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);            \
   } while (0)
-  const bool two = B > 64, mom = a.momentum != nullptr, first = mom && first_step;
-  if (two) { if (!mom) NNUE_UF_LAUNCH(true, false, false); else if (first) NNUE_UF_LAUNCH(true, true, true); else NNUE_UF_LAUNCH(true, true, false); }
-  else { if (!mom) NNUE_UF_LAUNCH(false, false, false); else if (first) NNUE_UF_LAUNCH(false, true, true); else NNUE_UF_LAUNCH(false, true, false); }
+  switch ((B + 63) / 64) {
+    case 1: NNUE_UF_LAUNCH(1); break;
+    case 2: NNUE_UF_LAUNCH(2); break;
+    case 4: NNUE_UF_LAUNCH(4); break;
+    case 8: NNUE_UF_LAUNCH(8); break;
+    default: NNUE_UF_LAUNCH(16); break;
+  }
 #undef NNUE_UF_LAUNCH
-  const int64_t count4 = (int64_t)B * L1 / 4;
+  const int64_t count4 = (int64_t)B_next * L1 / 4;
   hipLaunchKernelGGL(ftm_finish_kernel, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, st, static_cast<const float*>(scratch), s.ksplit, count4,
                      bias, weight + (size_t)(F - 1) * L1, sink_next, L1, out_next);
   return nnue_launch_status("nnue_ftm_backward_weight_update_forward");

@@ -30,8 +30,7 @@ struct UpdFwd {
   const float* __restrict__ coef;         // clip coefficient (device scalar)
   const float* __restrict__ lr_dev;       // NULL or the learning rate as a device scalar
   float* __restrict__ slabs;              // [ksplit][B][L1] split-K slabs of the next forward
-  const u32x4* __restrict__ dimg;         // NULL or d_out as LDS-ready bf16 plane images (uf_split_dout_kernel)
-  int B, P, L1, direct, klen, tiles_n, xcd_remap;
+  int B, Bn, P, L1, direct, klen, tiles_n, xcd_remap;  // B rows of the factors (bits, d_out), Bn rows of the next map / out'
   float lr, mom, wd, scale;
   int abl;  // timing-only ablations (NNUE_ABLATIONS builds): 1 no parameter/momentum loads, 2 no stores, 4 no forward phase, 8 no d_W MFMAs
 };
@@ -48,45 +47,17 @@ constexpr int kUfBs = 16384, kUfAn = 49152, kUfWpPlane = 16384;
 // land on sixteen different slots
 __device__ __forceinline__ int uf_wp_img(int row, int chunk) { return row * 256 + ((chunk ^ ((row ^ (row >> 2)) & 15)) << 4); }
 
-// d_out is the same operand for every table tile (and every workgroup of a column tile): it can be split ONCE per launch into
-// the three bf16 planes, stored as the byte image a K tile of it has in LDS (gemm_tile_bf64's B operand: per column tile j and
-// K tile kt, 3 planes x [64 n][64 k], 128-byte rows with the chunk swizzle of bf64_img) -- the main kernel then copies 16-byte
-// chunks linearly (no split: 152 of its ~1100 VALU instructions per table tile; it is bound by instruction issue, not by HBM).
-// grid (L1 / 64, ceil(B / 64)), 512 threads = 64 rows x 8 chunks.
-__global__ __launch_bounds__(512) void uf_split_dout_kernel(const float* __restrict__ d_out, int B, int L1, u32x4* __restrict__ img) {
-  const int j = blockIdx.x, kt = blockIdx.y, row = threadIdx.x & 63, c = threadIdx.x >> 6;
-  unsigned h[8], m[8], l[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int k = kt * 64 + 8 * c + e;
-    const float x = k < B ? d_out[(size_t)k * L1 + j * 64 + row] : 0.0f;
-    const unsigned hb = __float_as_uint(x) & 0xffff0000u;
-    const float r1 = x - __uint_as_float(hb);
-    const unsigned mb_ = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(mb_);
-    h[e] = hb; m[e] = mb_; l[e] = __float_as_uint(r2);
-  }
-  u32x4 ph, pm, pl;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    ph[t] = __builtin_amdgcn_perm(h[2 * t + 1], h[2 * t], 0x07060302u);
-    pm[t] = __builtin_amdgcn_perm(m[2 * t + 1], m[2 * t], 0x07060302u);
-    pl[t] = __builtin_amdgcn_perm(l[2 * t + 1], l[2 * t], 0x07060302u);
-  }
-  u32x4* __restrict__ dst = img + (size_t)(j * gridDim.y + kt) * 1536;  // 3 x 64 x 64 x 2 bytes = 1536 chunks
-  const int at = bf64_img(row, c) >> 4;
-  dst[at] = ph;
-  dst[512 + at] = pm;
-  dst[1024 + at] = pl;
-}
-
-// kTwo: B > 64, two K tiles of the weight-gradient product; kImg: d_out from the pre-split plane images; kMom: a momentum buffer;
-// kFirst: first step (momentum is written, not read).  Compile-time, and every load of the loop unconditional (a request past
+// kNK: K tiles (of 64 rows of the gradient's factors) of the weight-gradient product -- 2 at the 224x224 batch of 128; 4, 8, 16 when
+// the factors are the all-gathered ones of 2, 4, 8 ranks (data parallel by factor exchange: the update contracts the GLOBAL batch,
+// the next forward this rank's own next map); kMom: a momentum buffer; kFirst: first step (momentum is written, not read).
+// (d_out pre-split once per launch into LDS-ready plane images instead of in every workgroup and tile -- 152 of the ~1100 VALU
+// instructions per tile -- was built and measured: the kernel 222-225 vs 225-229 us, which its 2-3 us pre-pass gives back; removed,
+// profiles/r03s_uf_img_ab.txt.)  Compile-time, and every load of the loop unconditional (a request past
 // the workgroup's last tile is moved out of its buffer window: zeros, no memory traffic), because a runtime branch around a
 // memory instruction makes the compiler's wait counts the minimum over both paths: with such branches the waits for the map
 // tiles also drained the parameter and momentum loads that had been requested after them, i.e. the HBM latency was exposed
 // once per tile.
-template <bool kTwo, bool kMom, bool kFirst, bool kImg>
+template <int kNK, bool kMom, bool kFirst>
 __global__ __launch_bounds__(256, 2) void ftm_update_forward_kernel(UpdFwd a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[kUfLds];
   constexpr int KT = kBf64K, PB = 64 * KT * 2;
@@ -113,9 +84,9 @@ __global__ __launch_bounds__(256, 2) void ftm_update_forward_kernel(UpdFwd a) {
   }
   const int n_base = j * 64, p_lo = s * a.klen;
   const int p_hi = p_lo + a.klen < a.direct ? p_lo + a.klen : a.direct;
-  const int B = a.B, P = a.P, L1 = a.L1;
+  const int B = a.B, Bn = a.Bn, P = a.P, L1 = a.L1;
   const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.bits), 0, (unsigned)((size_t)B * P), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.bits_next), 0, (unsigned)((size_t)B * P), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.bits_next), 0, (unsigned)((size_t)Bn * P), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d_out), 0, (unsigned)((size_t)B * L1 * 4), 0x00020000);
   // parameters / momentum through buffer descriptors whose window ends at table row `direct`: rows past it read as zero and
   // their stores are dropped by the range check (no branches); non-temporal: touched once per step
@@ -144,27 +115,16 @@ __global__ __launch_bounds__(256, 2) void ftm_update_forward_kernel(UpdFwd a) {
   };
   coords();
   unsigned rat[8];
-  u32x4 rb[kImg ? 6 : 4];
-  // the plane images of this column tile: [K tile][1536 chunks] (a buffer window, so that a dead request can leave it)
-  const int nkt = (B + KT - 1) / KT;
-  const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.dimg) + (kImg ? (size_t)j * nkt * 1536 : 0), 0,
-                                                                       kImg ? (unsigned)(nkt * 1536 * 16) : 0u, 0x00020000);
+  u32x4 rb[4];
   auto fetch1 = [&](int m_base, int k0, bool live) {
     int base = live ? (k0 + ak8) * P + m_base + am4 : kOut;
     asm volatile("" : "+v"(base));  // (keeps the eight offsets as base + i P: one multiply, not eight)
 #pragma unroll
     for (int i = 0; i < 8; ++i) rat[i] = __builtin_amdgcn_raw_buffer_load_b32(rsa, base + i * P, 0, 0);
-    if constexpr (kImg) {
-      int bi = live ? ((k0 / KT) * 1536 + tid0) * 16 : kOut;
-      asm volatile("" : "+v"(bi));
+    int bb = live ? ((k0 + bk4) * L1 + n_base + bn4) * 4 : kOut;
+    asm volatile("" : "+v"(bb));
 #pragma unroll
-      for (int i = 0; i < 6; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsi, bi + i * 4096, 0, 0);
-    } else {
-      int bb = live ? ((k0 + bk4) * L1 + n_base + bn4) * 4 : kOut;
-      asm volatile("" : "+v"(bb));
-#pragma unroll
-      for (int i = 0; i < 4; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsb, bb + i * (L1 * 4), 0, 0);
-    }
+    for (int i = 0; i < 4; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsb, bb + i * (L1 * 4), 0, 0);
   };
   using u32x2 = __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned;
   auto stage1 = [&]() {
@@ -178,38 +138,33 @@ __global__ __launch_bounds__(256, 2) void ftm_update_forward_kernel(UpdFwd a) {
       }
       *reinterpret_cast<u32x4*>(As + bf64_img(am4 + e, ak8 >> 3)) = v;
     }
-    if constexpr (kImg) {
+    u32x2 pl[3][4];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) *reinterpret_cast<u32x4*>(Bs + (tid0 + 256 * i) * 16) = rb[i];  // the image as it lies in memory
-    } else {
-      u32x2 pl[3][4];
+    for (int t = 0; t < 2; ++t) {
+      unsigned h[2][4], m[2][4], l[2][4];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        unsigned h[2][4], m[2][4], l[2][4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float x = __uint_as_float(rb[2 * t + u][e]);
-            const unsigned hb = __float_as_uint(x) & 0xffff0000u;
-            const float r1 = x - __uint_as_float(hb);
-            const unsigned mb_ = __float_as_uint(r1) & 0xffff0000u;
-            const float r2 = r1 - __uint_as_float(mb_);
-            h[u][e] = hb; m[u][e] = mb_; l[u][e] = __float_as_uint(r2);
-          }
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          pl[0][e][t] = __builtin_amdgcn_perm(h[1][e], h[0][e], 0x07060302u);
-          pl[1][e][t] = __builtin_amdgcn_perm(m[1][e], m[0][e], 0x07060302u);
-          pl[2][e][t] = __builtin_amdgcn_perm(l[1][e], l[0][e], 0x07060302u);
+          const float x = __uint_as_float(rb[2 * t + u][e]);
+          const unsigned hb = __float_as_uint(x) & 0xffff0000u;
+          const float r1 = x - __uint_as_float(hb);
+          const unsigned mb_ = __float_as_uint(r1) & 0xffff0000u;
+          const float r2 = r1 - __uint_as_float(mb_);
+          h[u][e] = hb; m[u][e] = mb_; l[u][e] = __float_as_uint(r2);
         }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pl[0][e][t] = __builtin_amdgcn_perm(h[1][e], h[0][e], 0x07060302u);
+        pl[1][e][t] = __builtin_amdgcn_perm(m[1][e], m[0][e], 0x07060302u);
+        pl[2][e][t] = __builtin_amdgcn_perm(l[1][e], l[0][e], 0x07060302u);
       }
-      const int half = (bk4 & 4) ? 8 : 0;
-#pragma unroll
-      for (int pnum = 0; pnum < 3; ++pnum)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) *reinterpret_cast<u32x2*>(Bs + pnum * PB + bf64_img(bn4 + e, bk4 >> 3) + half) = pl[pnum][e];
     }
+    const int half = (bk4 & 4) ? 8 : 0;
+#pragma unroll
+    for (int pnum = 0; pnum < 3; ++pnum)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) *reinterpret_cast<u32x2*>(Bs + pnum * PB + bf64_img(bn4 + e, bk4 >> 3) + half) = pl[pnum][e];
   };
   // ---- phase 3: the next step's map tile, forward form (bytes contiguous along k = p): two 16-byte groups per thread and half
   auto an_row_of = [](int g) { const int x = g >> 2; return (x & ~3) | ((x & 1) << 1) | ((x >> 1) & 1); };
@@ -321,22 +276,24 @@ __global__ __launch_bounds__(256, 2) void ftm_update_forward_kernel(UpdFwd a) {
       for (int t = 0; t < 2; ++t) accw[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     stage1();
     __syncthreads();
-    if constexpr (kTwo) fetch1(m_base, KT, true);
-    fetch3(m_base, 0);
-#ifdef NNUE_ABLATIONS
-    if (!(a.abl & 8))
-#endif
-    contract1();
-    __syncthreads();
-    if constexpr (kTwo) {
-      stage1();
-      __syncthreads();
+    if constexpr (kNK == 1) fetch3(m_base, 0);
+#pragma unroll
+    for (int t = 1; t < kNK; ++t) {
+      fetch1(m_base, t * KT, true);
+      if (t == 1) fetch3(m_base, 0);
 #ifdef NNUE_ABLATIONS
       if (!(a.abl & 8))
 #endif
       contract1();
       __syncthreads();
+      stage1();
+      __syncthreads();
     }
+#ifdef NNUE_ABLATIONS
+    if (!(a.abl & 8))
+#endif
+    contract1();
+    __syncthreads();
     // ---------------- phase 2: accumulators -> LDS -> 8 rows x 4 columns per thread, SGD
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -423,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void ftm_update_forward_kernel(UpdFwd a) {
     __syncthreads();
   }
   // ---------------- the slab of the next forward (FwdEpi with ksplit > 1: plain stores)
-  float* __restrict__ dst = a.slabs + (size_t)s * B * L1;
+  float* __restrict__ dst = a.slabs + (size_t)s * Bn * L1;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int n = n_base + n0 + 16 * t + r;
@@ -432,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void ftm_update_forward_kernel(UpdFwd a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int m = m0 + 16 * i + 4 * q + e;
-        if (m < B) dst[(size_t)m * L1 + n] = accf[i][t][e];
+        if (m < Bn) dst[(size_t)m * L1 + n] = accf[i][t][e];
       }
   }
 }

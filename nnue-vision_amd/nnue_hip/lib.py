@@ -145,9 +145,9 @@ SIGNATURES = {
     "nnue_ftm_backward_tail_rows": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p]),
     "nnue_ftm_backward_weight_update": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_f, _c_f, _c_f, _c_f,
                                                  _c_int, _c_p, _c_p]),
-    "nnue_ftm_update_forward_supported": (_c_int, [_c_int, _c_int, _c_int, _c_int]),
+    "nnue_ftm_update_forward_supported": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int]),
     "nnue_ftm_backward_weight_update_forward": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_f, _c_f, _c_f, _c_f,
-                                                         _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
+                                                         _c_int, _c_p, _c_p, _c_p, _c_int, _c_p, _c_p, _c_p, _c_i64, _c_p]),
 }
 
 _lib: Optional[ctypes.CDLL] = None
@@ -1118,8 +1118,10 @@ def ftm_backward_weight_update(d_out: torch.Tensor, fm: "FeatureMatrix", weight:
           int(bool(first_step)), _ptr(lr_dev), _stream(d_out))
 
 
-def ftm_update_forward_supported(batch: int, num_rows: int, positions: int, l1: int) -> bool:
-    return bool(load().nnue_ftm_update_forward_supported(int(batch), int(num_rows), int(positions), int(l1)))
+def ftm_update_forward_supported(batch: int, num_rows: int, positions: int, l1: int, batch_next: Optional[int] = None) -> bool:
+    """batch: rows of the gradient's factors (the global batch under the factor exchange); batch_next: rows of the next map."""
+    return bool(load().nnue_ftm_update_forward_supported(int(batch), int(batch if batch_next is None else batch_next), int(num_rows),
+                                                         int(positions), int(l1)))
 
 
 def ftm_backward_weight_update_forward(d_out: torch.Tensor, fm: "FeatureMatrix", weight: torch.Tensor,
@@ -1132,13 +1134,13 @@ def ftm_backward_weight_update_forward(d_out: torch.Tensor, fm: "FeatureMatrix",
     b, l1 = d_out.shape
     weight = _need(weight, torch.float32, "input.weight", (fm.num_rows, l1))
     bias = _need(bias, torch.float32, "input.bias", (l1,))
-    out_next = _need(out_next, torch.float32, "out_next", (b, l1))
+    out_next = _need(out_next, torch.float32, "out_next", (fm_next.batch, l1))
     _need(coef, torch.float32, "clip coefficient")
-    if fm_next.batch != b or fm_next.positions != fm.positions or fm_next.num_rows != fm.num_rows:
-        raise ValueError("ftm_backward_weight_update_forward: the two maps must have the same shape")
+    if fm.batch != b or fm_next.positions != fm.positions or fm_next.num_rows != fm.num_rows:
+        raise ValueError("ftm_backward_weight_update_forward: the maps do not match d_out / each other")
     _call("nnue_ftm_backward_weight_update_forward", fm.bits.data_ptr(), d_out.data_ptr(), b, fm.num_rows, fm.positions, l1,
           weight.data_ptr(), _ptr(momentum_rows), coef.data_ptr(), float(lr), float(momentum), float(weight_decay), float(grad_scale),
-          int(bool(first_step)), _ptr(lr_dev), fm_next.bits.data_ptr(), fm_next.sink.data_ptr(), bias.data_ptr(), out_next.data_ptr(),
+          int(bool(first_step)), _ptr(lr_dev), fm_next.bits.data_ptr(), fm_next.sink.data_ptr(), fm_next.batch, bias.data_ptr(), out_next.data_ptr(),
           fm_next.scratch.data_ptr(), fm_next.scratch.numel(), _stream(d_out))
 
 

@@ -353,10 +353,13 @@ class NnueTrainer:
         # weights the small tensors' update has just written, and the update leaves every new table tile in registers) -- the
         # forward's own 268 MB read of the table disappears.  Two maps alternate (the update still reads step t's while step
         # t+1's is being written).  Bitwise the separate kernels.  NNUE_FUSE_NEXT_FORWARD=0 keeps them separate.
-        self.fuse_next_forward = (self.fuse_table_update and not self.fuse_l1 and self.K == 1
+        # (Under the factor exchange the update contracts the all-gathered GLOBAL batch, the next forward this rank's own next map.)
+        self.fuse_next_forward = ((self.fuse_table_update or self.factor_exchange) and not self.fuse_l1 and self.K == 1
                                   and os.environ.get("NNUE_FUSE_NEXT_FORWARD", "1") != "0"
-                                  and lib.ftm_update_forward_supported(B, self.F, self.P, self.L1))
+                                  and lib.ftm_update_forward_supported(gb if self.factor_exchange else B, self.F, self.P, self.L1, B))
         self.fm_alt = lib.FeatureMatrix.empty(B, self.P, self.F, self.L1, self.dev) if self.fuse_next_forward else None
+        if self.fm_alt is not None and self.fx is not None:
+            self.fm_alt.sink = self.fx.sink  # (both local maps' sink counts live in this rank's chunk: only one of them is live at a time)
         self._last_alt = False  # the last step's map is the second one (an even-length step group)
         self.d_z1 = self.ft_rider = None
         if self.ride_dw1 and self.K == 1:
@@ -545,12 +548,14 @@ class NnueTrainer:
                 lib.ftm_backward_weight_update(self.d_ft, self.fm, self.p["input.weight"], mom, self.clip_coef, self.lr, self.momentum,
                                                self.weight_decay, scale, first, lr_dev=self.lr_dev)
 
-    def _exchange_and_update(self, first: bool, grad_scale: Optional[float] = None) -> None:
+    def _exchange_and_update(self, first: bool, grad_scale: Optional[float] = None, alt: bool = False,
+                             next_slot: Optional[int] = None) -> None:
         """Everything after the local kernels of a data-parallel step, as launches on the current stream: the gradient
-        exchange and the optimizer.  Capturable (no host synchronisation)."""
+        exchange and the optimizer.  Capturable (no host synchronisation).  alt: this step's local map is the second one;
+        next_slot (step groups under the factor exchange): the table update also forms the forward of the step on that slot."""
         if self.factor_exchange:
             fx, scale = self.fx, (self.dp.grad_scale if grad_scale is None else grad_scale)
-            fx.pack(self.fm, self.flat_grads)
+            fx.pack(self.fm_alt if alt else self.fm, self.flat_grads)
             self.dp.all_gather_chunks(fx.chunks)  # the step's one collective
             fx.unpack(self.flat_grads)
             lib.ftm_gram_sqnorm(fx.g_fm, fx.g_dft, self.gram, self.sq_partial)
@@ -559,6 +564,14 @@ class NnueTrainer:
                          coef_out=self.clip_coef, ext_applied_elsewhere=True, lr_dev=self.lr_dev)
             lo, hi = self.sq_range
             mom = self.flat_momentum[lo:hi] if self.flat_momentum is not None else None
+            if next_slot is not None:
+                nxt = self.fm if alt else self.fm_alt
+                lib.ftm_conv_binarize(self.inputs[next_slot][0], self.p["conv.weight"], self.p["visual_threshold"], self.stride, self.F, self.L1,
+                                      conv_out=self.conv_out, fm=nxt, patches=self.patches,
+                                      write_conv_out=not (self.use_patches and self.reform_conv_out))
+                lib.ftm_backward_weight_update_forward(fx.g_dft, fx.g_fm, self.p["input.weight"], mom, self.clip_coef, self.lr, self.momentum,
+                                                       self.weight_decay, scale, first, nxt, self.p["input.bias"], self.ft, lr_dev=self.lr_dev)
+                return
             lib.ftm_backward_weight_update(fx.g_dft, fx.g_fm, self.p["input.weight"], mom, self.clip_coef, self.lr, self.momentum,
                                            self.weight_decay, scale, first, lr_dev=self.lr_dev)
             return
@@ -835,13 +848,13 @@ class NnueTrainer:
     def _run_many(self, st: torch.cuda.Stream, slots, ring: torch.Tensor, upd, timers=None) -> None:
         """The launches of ``len(slots)`` consecutive steps on stream `st` (the current stream): what step_many captures, and
         -- with `timers` -- what it runs eagerly with HIP events around the named entry points."""
-        fuse = self.fuse_next_forward and len(slots) > 1 and not self.dp.collectives
+        fuse = self.fuse_next_forward and len(slots) > 1 and (not self.dp.collectives or self.factor_exchange)
         for i, s in enumerate(slots):
             alt = fuse and i % 2 == 1
             self._run_local(s, "all", st, branch=False, timers=timers, loss=ring[i], alt=alt, forward_done=fuse and i > 0)
             if self.dp.collectives:
                 with lib.time_calls(timers):
-                    self._exchange_and_update(False)
+                    self._exchange_and_update(False, alt=alt, next_slot=slots[i + 1] if fuse and i + 1 < len(slots) else None)
             elif fuse and i + 1 < len(slots):
                 # small tensors (and the clip coefficient) first: the next map needs the updated conv weights and thresholds,
                 # the next forward's finish the updated bias and table row F-1
@@ -913,7 +926,7 @@ class NnueTrainer:
             return self.loss_ring[:len(slots)]
         graph, ring = self._g_local[(slots, "many")]
         graph.replay()
-        self._last_alt = self.fuse_next_forward and len(slots) % 2 == 0 and not self.dp.collectives
+        self._last_alt = self.fuse_next_forward and len(slots) % 2 == 0 and (not self.dp.collectives or self.factor_exchange)
         self.steps_done += len(slots)
         return ring[:len(slots)]
 

@@ -161,7 +161,13 @@ def test_three_steps_at_the_baseline_shape_follow_the_oracle(name, expect_factor
     assert float(model.nnue2score) == 600.0
 
 
-def test_a_step_group_at_the_224_shape_follows_the_oracle():
+def test_a_step_group_at_the_224_shape_through_the_factor_exchange(one_rank_rccl):
+    """The same group under data parallel: factors all-gathered and the collective captured in the group's graph, the table update on
+    the gathered factors also forming this rank's next forward."""
+    test_a_step_group_at_the_224_shape_follows_the_oracle(expect_factor_exchange=True)
+
+
+def test_a_step_group_at_the_224_shape_follows_the_oracle(expect_factor_exchange=False):
     """BASELINE configs[3]'s shape as bench.py runs it: a group of steps replayed as one hipGraph in which the table update of a
     step also forms the next step's FeatureTransformer forward (nnue_ftm_backward_weight_update_forward, two alternating maps).
     One single step (records the plans), then a group of three, against four oracle steps."""
@@ -173,6 +179,7 @@ def test_a_step_group_at_the_224_shape_follows_the_oracle():
     stride = orc.conv_stride(cfg["image"], cfg["grid"])
     tr = NnueTrainer(model.to(DEV), cfg["batch"], (cfg["image"], cfg["image"]), use_graph=True, input_slots=3, **OPT)
     import os
+    assert tr.factor_exchange == expect_factor_exchange and (not expect_factor_exchange or tr.capture_collectives)
     if not tr.fuse_next_forward:
         assert os.environ.get("NNUE_FUSE_NEXT_FORWARD") == "0" or os.environ.get("NNUE_FUSE_TABLE_UPDATE") == "0" \
             or os.environ.get("NNUE_FT_PATH", "auto") not in ("auto", "mfma") or os.environ.get("NNUE_FTM_BF16") == "0" \

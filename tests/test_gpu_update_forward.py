@@ -21,20 +21,24 @@ def _map(lib, gen, b, p, f, l1, density=0.42):
     return fm
 
 
-# (B, F, P, L1): split-K forward over >= 4096 table rows; ragged batch, table rows that are no multiple of a tile, a clamp
-# sink (P > F - 1), and the 224x224 shape itself
-SHAPES = [(128, 8192, 8192, 256), (100, 9001, 9000, 256), (128, 5000, 8192, 128), (64, 16400, 16400, 192), (128, 65536, 65536, 1024)]
+# (B, F, P, L1[, B_next]): split-K forward over >= 4096 table rows; ragged batch, table rows that are no multiple of a tile, a
+# clamp sink (P > F - 1), the 224x224 shape itself, and the factor exchange's shapes (B = the all-gathered global batch of 2, 4
+# and 8 ranks: 4, 8, 16 K tiles in the weight-gradient product; B_next = this rank's next batch)
+SHAPES = [(128, 8192, 8192, 256), (100, 9001, 9000, 256), (128, 5000, 8192, 128), (64, 16400, 16400, 192), (128, 65536, 65536, 1024),
+          (256, 8192, 8192, 256, 128), (500, 8192, 8192, 256, 125), (1024, 8192, 8192, 256, 128)]
 
 
-@pytest.mark.parametrize("b,f,p,l1", SHAPES)
+@pytest.mark.parametrize("shape", SHAPES)
 @pytest.mark.parametrize("first,mom", [(False, 0.9), (True, 0.9), (False, 0.0)])
-def test_bitwise_the_two_separate_calls(b, f, p, l1, first, mom):
+def test_bitwise_the_two_separate_calls(shape, first, mom):
     from nnue_hip import lib
     lib.load()
-    if not lib.ftm_update_forward_supported(b, f, p, l1):
+    b, f, p, l1 = shape[:4]
+    bn = shape[4] if len(shape) > 4 else b
+    if not lib.ftm_update_forward_supported(b, f, p, l1, bn):
         pytest.skip("shape is not a split-K forward over a big table")
     gen = torch.Generator().manual_seed(b * 7 + f)
-    fm, fm_next = _map(lib, gen, b, p, f, l1), _map(lib, gen, b, p, f, l1, density=0.3)
+    fm, fm_next = _map(lib, gen, b, p, f, l1), _map(lib, gen, bn, p, f, l1, density=0.3)
     d_out = (torch.randn(b, l1, generator=gen) * 0.05).to(DEV)
     weight = (torch.randn(f, l1, generator=gen) * 0.1).to(DEV)
     momentum = (torch.randn(f, l1, generator=gen) * 0.01).to(DEV) if mom else None
@@ -49,7 +53,7 @@ def test_bitwise_the_two_separate_calls(b, f, p, l1, first, mom):
     torch.cuda.synchronize()
 
     w_got, m_got = weight.clone(), (momentum.clone() if mom else None)
-    out_got = torch.full((b, l1), float("nan"), device=DEV)
+    out_got = torch.full((bn, l1), float("nan"), device=DEV)
     fm_next.scratch.zero_()
     for _ in range(2 if first else 1):  # twice from the same state when nothing accumulates (first step ignores momentum)
         w_got.copy_(weight)
@@ -100,13 +104,15 @@ def test_argument_errors():
     import os
     if os.environ.get("NNUE_FTM_BF16") == "0" or os.environ.get("NNUE_FTM_BF_KT64") == "0":
         pytest.skip("a developer knob took the forward off the tiles the fused pass is built on")
-    assert L.nnue_ftm_update_forward_supported(128, 65536, 65536, 1024) == 1
-    assert L.nnue_ftm_update_forward_supported(512, 800, 968, 1024) == 0      # launch-sized table
-    assert L.nnue_ftm_update_forward_supported(256, 65536, 65536, 1024) == 0  # batch wider than one forward tile
-    assert L.nnue_ftm_update_forward_supported(128, 65536, 65536, 1000) == 0  # L1 % 64
+    assert L.nnue_ftm_update_forward_supported(128, 128, 65536, 65536, 1024) == 1
+    assert L.nnue_ftm_update_forward_supported(1024, 128, 65536, 65536, 1024) == 1  # eight ranks' factors
+    assert L.nnue_ftm_update_forward_supported(512, 512, 800, 968, 1024) == 0        # launch-sized table
+    assert L.nnue_ftm_update_forward_supported(256, 256, 65536, 65536, 1024) == 0    # next batch wider than one forward tile
+    assert L.nnue_ftm_update_forward_supported(384, 128, 65536, 65536, 1024) == 0    # six K tiles: not one of 1, 2, 4, 8, 16
+    assert L.nnue_ftm_update_forward_supported(128, 128, 65536, 65536, 1000) == 0    # L1 % 64
     z = torch.zeros(1 << 16, device=DEV)
     u = torch.zeros(1 << 16, dtype=torch.uint8, device=DEV)
     args = (u.data_ptr(), z.data_ptr(), 8, 800, 968, 64, z.data_ptr(), 0, z.data_ptr(), 0.1, 0.0, 0.0, 1.0, 0, 0, u.data_ptr() + 4096, z.data_ptr(),
-            z.data_ptr(), z.data_ptr(), z.data_ptr(), 1 << 16, 0)
+            8, z.data_ptr(), z.data_ptr(), z.data_ptr(), 1 << 16, 0)
     assert L.nnue_ftm_backward_weight_update_forward(*args) != 0
     assert b"split-K" in L.nnue_hip_last_error()
