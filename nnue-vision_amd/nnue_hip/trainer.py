@@ -889,12 +889,13 @@ class NnueTrainer:
         slots = tuple(int(s) for s in slots)
         if not slots or min(slots) < 0 or max(slots) >= len(self.inputs):
             raise ValueError(f"slots must name input slots 0..{len(self.inputs) - 1}")
-        if timers is not None and self.steps_done > 0 and self._plan_local is not None and not self.dp.collectives:
+        if timers is not None and self.steps_done > 0 and self._plan_local is not None:
+            # (with ranks: the collectives are issued eagerly, in the same order on every rank)
             _, _, upd = self._plans(slots[0])
             if self.loss_ring.numel() < len(slots):
                 self.loss_ring = torch.zeros((len(slots),), dtype=torch.float32, device=self.dev)
             self._run_many(torch.cuda.current_stream(self.dev), slots, self.loss_ring, upd, timers)
-            self._last_alt = self.fuse_next_forward and len(slots) % 2 == 0
+            self._last_alt = self.fuse_next_forward and len(slots) % 2 == 0 and (not self.dp.collectives or self.factor_exchange)
             self.steps_done += len(slots)
             return self.loss_ring[:len(slots)]
         one_graph = (self.use_graph and self.steps_done > 0 and self._plan_local is not None

@@ -190,3 +190,72 @@ def test_two_ranks_over_rccl(tmp_path, env):
     _run(tmp_path, 2, "nccl", True, env)
     _run(tmp_path, 2, "nccl", True, env, short_last=True)
     _run(tmp_path, 2, "nccl", True, {**env, "TEST_STEP_MANY": "1"})
+
+
+# ---- the fused table update + next forward under the factor exchange with MORE than one rank (gloo, the ranks share the GPU):
+# a table the forward walks as a split-K product (64x64 images, 16x16x32 map, 8192 rows x 256), 128 images per rank -> the update
+# contracts 256 gathered rows (four K tiles), the next forward this rank's own 128
+BIG = dict(grid=16, fps=32, l1=256, l2=32, l3=16, classes=10, hw=64, per_rank=128)
+
+
+def _big_batch(step, n):
+    gen = torch.Generator().manual_seed(900 + step)
+    return torch.randn(n, 3, BIG["hw"], BIG["hw"], generator=gen), torch.randint(0, BIG["classes"], (n,), generator=gen)
+
+
+def _big_model(device):
+    for p in (str(ROOT / "nnue-vision_amd"),):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import nnue
+    torch.manual_seed(0)
+    return nnue.NNUE(nnue.GridFeatureSet(BIG["grid"], BIG["fps"]), BIG["l1"], BIG["l2"], BIG["l3"], num_classes=BIG["classes"],
+                     input_size=BIG["hw"]).to(device)
+
+
+def _big_worker(rank, port, out_dir, world):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", NNUE_DP_FACTOR_EXCHANGE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nnue_hip.trainer import NnueTrainer
+        tr = NnueTrainer(_big_model(torch.device("cuda", 0)), BIG["per_rank"], (BIG["hw"], BIG["hw"]), use_graph=False, input_slots=3, **OPT)
+        assert tr.factor_exchange and tr.fuse_next_forward and tr.fm_alt.sink.data_ptr() == tr.fx.sink.data_ptr()
+        sl = slice(rank * BIG["per_rank"], (rank + 1) * BIG["per_rank"])
+        images, labels = _big_batch(0, BIG["per_rank"] * world)
+        losses = [float(tr.step(images[sl].cuda(), labels[sl].cuda(), slot=0))]
+        for s in range(3):
+            images, labels = _big_batch(1 + s, BIG["per_rank"] * world)
+            tr.inputs[s][0].copy_(images[sl])
+            tr.inputs[s][1].copy_(labels[sl])
+        timers = {"nnue_ftm_backward_weight_update_forward": [], "nnue_ftm_backward_weight_update": []}
+        losses += [float(v) for v in tr.step_many((0, 1, 2), timers=timers)]  # the group's launches, eagerly (gloo cannot be captured)
+        assert len(timers["nnue_ftm_backward_weight_update_forward"]) == 2 and len(timers["nnue_ftm_backward_weight_update"]) == 1
+        torch.cuda.synchronize()
+        torch.save({"flat": tr.flat_params.cpu(), "losses": losses}, Path(out_dir) / f"big{rank}.pt")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_step_group_with_the_fused_update_and_next_forward(tmp_path):
+    """Two ranks, factor exchange, one single step then a group of three whose table updates also form the next forwards (issued
+    eagerly: gloo): bitwise identical replicas and the trajectory of one process on the global batch."""
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_big_worker, args=(port, str(tmp_path), world), nprocs=world, join=True)
+    ranks = [torch.load(tmp_path / f"big{r}.pt", weights_only=True) for r in range(world)]
+    assert torch.equal(ranks[0]["flat"], ranks[1]["flat"]), "replicas diverged"
+    from nnue_hip.trainer import NnueTrainer
+    ref = NnueTrainer(_big_model(torch.device("cuda", 0)), BIG["per_rank"] * world, (BIG["hw"], BIG["hw"]), use_graph=False, **OPT)
+    ref_losses = []
+    for s in range(4):
+        images, labels = _big_batch(s, BIG["per_rank"] * world)
+        ref_losses.append(float(ref.step(images.cuda(), labels.cuda())))
+    got, want = ranks[0]["flat"][:ref.layout.count], ref.flat_params.cpu()[:ref.layout.count]
+    assert float((got - want).abs().max()) <= 2e-4 * float(want.abs().max())
+    for s in range(4):
+        mean = sum(r["losses"][s] for r in ranks) / world
+        assert abs(mean - ref_losses[s]) <= 2e-4 * max(1.0, abs(ref_losses[s])), (s, mean, ref_losses[s])
